@@ -1,0 +1,250 @@
+"""Python binding of the C ABI in include/hmp3_amd.h (hmp3_amd/libhmp3amd.so).
+
+The library is the product: hand-written HIP kernels for gfx950 behind a C ABI.  This module
+only loads it (ctypes) and mirrors the reference's CMp3Enc interface for tests / bench.  There
+is no CPU fallback: if the library or a GPU is missing, calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhmp3amd.so")
+
+
+class EControl(C.Structure):
+    """E_CONTROL (reference pub/encapp.h:42-72)"""
+    _fields_ = [(n, C.c_int) for n in (
+        "mode", "bitrate", "samprate", "nsbstereo", "filter_select", "freq_limit", "nsb_limit",
+        "layer", "cr_bit", "original", "hf_flag", "vbr_flag", "vbr_mnr", "vbr_br_limit",
+        "vbr_delta_mnr", "chan_add_f0", "chan_add_f1", "sparse_scale")] + \
+        [("mnr_adjust", C.c_int * 21)] + \
+        [(n, C.c_int) for n in ("cpu_select", "quick", "test1", "test2", "test3", "short_block_threshold")]
+
+
+class MpegHead(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sync", "id", "option", "prot", "br_index", "sr_index", "pad",
+                                       "private_bit", "mode", "mode_ext", "cr", "original", "emphasis")]
+
+
+class InOut(C.Structure):
+    _fields_ = [("in_bytes", C.c_int), ("out_bytes", C.c_int)]
+
+
+class IntPair(C.Structure):
+    _fields_ = [("a", C.c_int), ("b", C.c_int)]
+
+
+EXPORTS = [
+    "hx_last_error", "hx_device_count", "hx_default_control",
+    "hx_enc_create", "hx_enc_destroy", "hx_enc_L3_audio_encode_init", "hx_enc_L3_audio_encode",
+    "hx_enc_MP3_audio_encode_init", "hx_enc_MP3_audio_encode", "hx_enc_get_bitrate",
+    "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
+    "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
+    "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
+    "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_status",
+    "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
+]
+
+_lib = None
+
+
+def lib():
+    """load libhmp3amd.so (raises if it has not been built: run hmp3_amd/build.sh)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("hmp3_amd/libhmp3amd.so is missing - build it with hmp3_amd/build.sh "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.hx_last_error.restype = C.c_char_p
+        L.hx_default_control.argtypes = [C.POINTER(EControl)]
+        L.hx_enc_create.restype = C.c_void_p
+        L.hx_enc_create.argtypes = [C.c_int]
+        L.hx_enc_destroy.argtypes = [C.c_void_p]
+        L.hx_enc_L3_audio_encode_init.argtypes = [C.c_void_p, C.POINTER(EControl)]
+        L.hx_enc_L3_audio_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hx_enc_L3_audio_encode.restype = InOut
+        L.hx_enc_MP3_audio_encode_init.argtypes = [C.c_void_p, C.POINTER(EControl), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.hx_enc_MP3_audio_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hx_enc_MP3_audio_encode.restype = InOut
+        L.hx_enc_get_bitrate.argtypes = [C.c_void_p]
+        L.hx_enc_get_bitrate_float.argtypes = [C.c_void_p]
+        L.hx_enc_get_bitrate_float.restype = C.c_float
+        L.hx_enc_get_bitrate2_float.argtypes = [C.c_void_p]
+        L.hx_enc_get_bitrate2_float.restype = C.c_float
+        L.hx_enc_get_frames.argtypes = [C.c_void_p]
+        L.hx_enc_get_frames.restype = C.c_uint
+        L.hx_enc_get_frames_bytes.argtypes = [C.c_void_p]
+        L.hx_enc_get_frames_bytes.restype = IntPair
+        L.hx_enc_info_ec.argtypes = [C.c_void_p, C.POINTER(EControl)]
+        L.hx_enc_info_head.argtypes = [C.c_void_p, C.POINTER(MpegHead)]
+        L.hx_enc_info_string.argtypes = [C.c_void_p, C.c_char_p]
+        L.hx_batch_create.restype = C.c_void_p
+        L.hx_batch_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.hx_batch_destroy.argtypes = [C.c_void_p]
+        L.hx_batch_nstreams.argtypes = [C.c_void_p]
+        L.hx_batch_out_stride.argtypes = [C.c_void_p, C.c_int]
+        L.hx_batch_out_stride.restype = C.c_longlong
+        L.hx_batch_encode_s16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.hx_batch_encode_s16_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_batch_status.argtypes = [C.c_void_p]
+        L.hx_batch_frames_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.hx_batch_frames_bytes.restype = IntPair
+        L.hx_batch_alloc_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.hx_batch_alloc_kernel_ms.restype = C.c_float
+        L.hx_batch_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_longlong]
+        L.hx_batch_debug_read.restype = C.c_longlong
+        L.hx_batch_debug_enable.argtypes = [C.c_void_p, C.c_int]
+        L.hx_debug_host_table.argtypes = [C.POINTER(EControl), C.c_char_p, C.c_void_p, C.c_longlong]
+        L.hx_debug_host_table.restype = C.c_longlong
+        _lib = L
+    return _lib
+
+
+def default_control(**kw):
+    """CLI defaults (reference test/tomp3.cpp:357-384); bitrate=N per channel selects CBR (-B N)"""
+    ec = EControl()
+    lib().hx_default_control(C.byref(ec))
+    for k, v in kw.items():
+        setattr(ec, k, v)
+    if kw.get("bitrate", -1) > 0 and "vbr_flag" not in kw:
+        ec.vbr_flag = 0
+    return ec
+
+
+def last_error():
+    return lib().hx_last_error().decode()
+
+
+class Batch:
+    """N independent streams on one GPU (hx_batch_*)."""
+
+    def __init__(self, controls, nstreams=None, max_frames=256, device=0):
+        L = lib()
+        if isinstance(controls, EControl):
+            self.n = int(nstreams)
+            self._ec = controls
+            self.h = L.hx_batch_create(device, self.n, C.byref(controls), 1, max_frames)
+        else:
+            self.n = len(controls)
+            arr = (EControl * self.n)(*controls)
+            self._ec = arr
+            self.h = L.hx_batch_create(device, self.n, arr, 0, max_frames)
+        if not self.h:
+            raise RuntimeError("hx_batch_create failed: " + last_error())
+        self.max_frames = max_frames
+
+    def out_stride(self, nframes):
+        return int(lib().hx_batch_out_stride(self.h, nframes))
+
+    def encode_host(self, pcm):
+        """pcm: int16 [n, nframes*1152, 2] -> list of bytes per stream"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        assert pcm.shape[0] == self.n and pcm.shape[2] == 2 and pcm.shape[1] % 1152 == 0
+        nfr = pcm.shape[1] // 1152
+        stride = self.out_stride(nfr)
+        out = np.zeros((self.n, stride), dtype=np.uint8)
+        nb = np.zeros(self.n, dtype=np.int32)
+        r = lib().hx_batch_encode_s16_host(self.h, pcm.ctypes.data, nfr, out.ctypes.data, stride, nb.ctypes.data)
+        if r != 0:
+            raise RuntimeError("hx_batch_encode_s16_host failed: " + last_error())
+        return [out[i, :nb[i]].tobytes() for i in range(self.n)]
+
+    def encode_device(self, d_pcm_ptr, nframes, d_out_ptr, out_stride, d_out_bytes_ptr, stream=None):
+        r = lib().hx_batch_encode_s16_device(self.h, d_pcm_ptr, nframes, d_out_ptr, out_stride, d_out_bytes_ptr, stream)
+        if r != 0:
+            raise RuntimeError("hx_batch_encode_s16_device failed: " + last_error())
+
+    def status(self):
+        return int(lib().hx_batch_status(self.h))
+
+    def frames_bytes(self, i):
+        p = lib().hx_batch_frames_bytes(self.h, i)
+        return p.a, p.b
+
+    def alloc_kernel_ms(self):
+        n = C.c_int(0)
+        ms = lib().hx_batch_alloc_kernel_ms(self.h, C.byref(n))
+        return float(ms), n.value
+
+    def debug_enable(self, on=True):
+        lib().hx_batch_debug_enable(self.h, 1 if on else 0)
+
+    def debug_read(self, name, dtype, count):
+        a = np.zeros(count, dtype=dtype)
+        n = lib().hx_batch_debug_read(self.h, name.encode(), a.ctypes.data, a.nbytes)
+        if n < 0:
+            raise RuntimeError("unknown debug buffer " + name)
+        return a[: n // a.itemsize]
+
+    def close(self):
+        if self.h:
+            lib().hx_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mp3Enc:
+    """Same surface as the reference's CMp3Enc (pub/mp3enc.h:74-139), one stream."""
+
+    def __init__(self, device=0):
+        self.h = lib().hx_enc_create(device)
+        self._out = (C.c_ubyte * (1 << 17))()
+
+    def L3_audio_encode_init(self, ec):
+        return lib().hx_enc_L3_audio_encode_init(self.h, C.byref(ec))
+
+    def MP3_audio_encode_init(self, ec, source_bits=16, source_is_float=0, mpeg_select=0, mono_convert=0):
+        return lib().hx_enc_MP3_audio_encode_init(self.h, C.byref(ec), source_bits, source_is_float, mpeg_select, mono_convert)
+
+    def L3_audio_encode(self, pcm_f32):
+        pcm = np.ascontiguousarray(pcm_f32, dtype=np.float32)
+        x = lib().hx_enc_L3_audio_encode(self.h, pcm.ctypes.data, self._out)
+        return x.in_bytes, bytes(self._out[: x.out_bytes])
+
+    def MP3_audio_encode(self, pcm_i16):
+        pcm = np.ascontiguousarray(pcm_i16, dtype=np.int16)
+        x = lib().hx_enc_MP3_audio_encode(self.h, pcm.ctypes.data, self._out)
+        return x.in_bytes, bytes(self._out[: x.out_bytes])
+
+    def L3_audio_encode_get_frames(self):
+        return int(lib().hx_enc_get_frames(self.h))
+
+    def L3_audio_encode_get_bitrate_float(self):
+        return float(lib().hx_enc_get_bitrate_float(self.h))
+
+    def L3_audio_encode_get_frames_bytes(self):
+        p = lib().hx_enc_get_frames_bytes(self.h)
+        return p.a, p.b
+
+    def L3_audio_encode_info_ec(self):
+        ec = EControl()
+        lib().hx_enc_info_ec(self.h, C.byref(ec))
+        return ec
+
+    def L3_audio_encode_info_head(self):
+        h = MpegHead()
+        lib().hx_enc_info_head(self.h, C.byref(h))
+        return h
+
+    def L3_audio_encode_info_string(self):
+        s = C.create_string_buffer(160)
+        lib().hx_enc_info_string(self.h, s)
+        return s.value.decode()
+
+    def close(self):
+        if self.h:
+            lib().hx_enc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build the MI355X encoder library in-tree: hmp3_amd/libhmp3amd.so (gfx950 only).
+# -ffp-contract=off: the kernels must not fuse multiply-adds (bit-exactness against the oracle).
+set -e
+cd "$(dirname "$0")/csrc"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
+$HIPCC $FLAGS -c hx_front.hip -o hx_front.o
+$HIPCC $FLAGS -c hx_alloc.hip -o hx_alloc.o
+$HIPCC $FLAGS -c hx_cabi.hip -o hx_cabi.o
+g++ -O2 -fPIC -ffp-contract=off -std=c++17 -c hx_host.cpp -o hx_host.o
+$HIPCC --offload-arch=gfx950 -shared -o ../libhmp3amd.so hx_front.o hx_alloc.o hx_cabi.o hx_host.o
+rm -f *.o
+echo built hmp3_amd/libhmp3amd.so

@@ -1,0 +1,448 @@
+// hx_cabi.hip - C ABI (include/hmp3_amd.h) and launch sequence of the batched encoder.
+// Host runtime: owns the device buffers of a batch (subband carry, spectra, psy data, stream
+// state), groups streams into configuration classes and launches K1..K8 on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <string>
+#include "../../include/hmp3_amd.h"
+#include "hx_types.h"
+#include "hx_host.h"
+
+// kernels (hx_front.hip / hx_alloc.hip)
+#define K1_GPB 14
+__global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
+                            const HxGlobalTabs *gt, float *sb, int NG, int SG);
+__global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total);
+__global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
+                             int *dbg_metric, int NG, int total);
+__global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, int NG, int S, int *status);
+__global__ void k_mdct(const float *sb, const HxStream *st, const HxParams *prm, const unsigned char *bt,
+                       float *xr, int NG, int SG, long long units);
+__global__ void k_psy(const float *xr, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
+                      float *etab, float *thr, int NG);
+__global__ void k_msmetric(const float *xr, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
+                           int *msbase, int NG);
+__global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S);
+struct AllocArgs {
+    HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
+    const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt;
+    unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status;
+};
+__global__ void k_alloc(AllocArgs a);
+
+static thread_local std::string g_err;
+static void set_err(const char *fmt, const char *a = "")
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), fmt, a);
+    g_err = buf;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("HIP error: %s", hipGetErrorString(e_)); return -1; } } while (0)
+#define HIPCHKN(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("HIP error: %s", hipGetErrorString(e_)); return nullptr; } } while (0)
+
+struct hx_batch {
+    int device = 0, S = 0, maxF = 0, ncls = 0;
+    std::vector<HxParams> params;       // host copy per class
+    std::vector<int> cls_of;            // stream -> class
+    HxParams *d_prm = nullptr;
+    HxGlobalTabs *d_gt = nullptr;
+    HxStream *d_st = nullptr;
+    float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
+    int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
+    unsigned char *d_flg = nullptr, *d_bt = nullptr;
+    HxFrameDebug *d_dbg = nullptr;
+    int lastNG = 0;                     // NG of the previous call (layout of the carry)
+    bool debug = false;
+    // staging for the host-buffer entry points
+    int16_t *d_pcm = nullptr; unsigned char *d_out = nullptr; int *d_outbytes = nullptr;
+    long long pcm_cap = 0, out_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double alloc_ms_sum = 0; int alloc_calls = 0;
+};
+
+extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void hx_default_control(HX_E_CONTROL *ec) { hx_host_default_control((HxControl *) ec); }
+
+extern "C" void hx_batch_destroy(hx_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
+                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (auto &pr : b->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete b;
+}
+
+extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTROL *ec, int shared_control, int max_frames)
+{
+    if (nstreams <= 0 || max_frames <= 0 || !ec) { set_err("bad arguments"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err("no HIP device available: the encoder has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= ndev) { set_err("device index out of range"); return nullptr; }
+    HIPCHKN(hipSetDevice(device));
+    hx_batch *b = new hx_batch;
+    b->device = device; b->S = nstreams; b->maxF = max_frames;
+    b->cls_of.resize(nstreams);
+    // group streams into configuration classes
+    std::vector<HxControl> seen;
+    for (int s = 0; s < nstreams; s++) {
+        const HxControl *c = (const HxControl *) (shared_control ? ec : ec + s);
+        int k = -1;
+        for (size_t i = 0; i < seen.size(); i++) if (memcmp(&seen[i], c, sizeof(HxControl)) == 0) { k = (int) i; break; }
+        if (k < 0) {
+            HxParams p;
+            if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: MPEG-1 stereo / joint stereo without intensity only)"); delete b; return nullptr; }
+            if (p.filter_dc) { set_err("filter_select=1 (DC blocker) is not on the GPU path yet"); delete b; return nullptr; }
+            seen.push_back(*c);
+            b->params.push_back(p);
+            k = (int) seen.size() - 1;
+        }
+        b->cls_of[s] = k;
+        if (shared_control) { for (int t = 1; t < nstreams; t++) b->cls_of[t] = 0; break; }
+    }
+    b->ncls = (int) b->params.size();
+    const long long S = nstreams, NG = 2LL * max_frames;
+    HxGlobalTabs gt;
+    hx_global_tabs(&gt);
+    std::vector<HxStream> st(nstreams);
+    for (int s = 0; s < nstreams; s++) hx_stream_reset(&b->params[b->cls_of[s]], b->cls_of[s], &st[s]);
+#define ALLOC(ptr, bytes) do { if (hipMalloc((void **) &(ptr), (size_t) (bytes)) != hipSuccess) { set_err("hipMalloc failed"); hx_batch_destroy(b); return nullptr; } } while (0)
+    ALLOC(b->d_prm, sizeof(HxParams) * b->ncls);
+    ALLOC(b->d_gt, sizeof(HxGlobalTabs));
+    ALLOC(b->d_st, sizeof(HxStream) * S);
+    ALLOC(b->d_sb, sizeof(float) * S * 2 * (NG + 3) * 576);
+    ALLOC(b->d_xr, sizeof(float) * S * NG * 1152);
+    ALLOC(b->d_etab, sizeof(float) * S * NG * 128);
+    ALLOC(b->d_thr, sizeof(float) * S * NG * 128);
+    ALLOC(b->d_eng, sizeof(int) * S * 2 * NG * 9);
+    ALLOC(b->d_msbase, sizeof(int) * S * NG);
+    ALLOC(b->d_flg, S * NG);
+    ALLOC(b->d_bt, S * NG);
+    ALLOC(b->d_status, sizeof(int));
+    ALLOC(b->d_outbytes, sizeof(int) * S);
+    HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
+    HIPCHKN(hipMemcpy(b->d_gt, &gt, sizeof(gt), hipMemcpyHostToDevice));
+    HIPCHKN(hipMemcpy(b->d_st, st.data(), sizeof(HxStream) * S, hipMemcpyHostToDevice));
+    HIPCHKN(hipMemset(b->d_sb, 0, sizeof(float) * S * 2 * (NG + 3) * 576));
+    HIPCHKN(hipMemset(b->d_status, 0, sizeof(int)));
+    b->lastNG = 0;
+    return b;
+}
+
+extern "C" int hx_batch_nstreams(const hx_batch *b) { return b ? b->S : 0; }
+
+extern "C" long long hx_batch_out_stride(const hx_batch *b, int nframes)
+{
+    // a call can flush up to 31 pending frames plus its own; largest MPEG-1 frame is 1441 bytes
+    int maxframe = 0;
+    for (const HxParams &p : b->params) {
+        int fb = p.vbr_flag ? p.vbr_framebytes[p.ivbr_max] : p.framebytes + 1;
+        if (fb > maxframe) maxframe = fb;
+    }
+    long long n = (long long) (nframes + 2) * maxframe;
+    return (n + 255) & ~255LL;
+}
+
+extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
+{
+    b->debug = on != 0;
+    if (on && !b->d_dbg) {
+        hipSetDevice(b->device);
+        hipMalloc((void **) &b->d_dbg, sizeof(HxFrameDebug) * (size_t) b->S * b->maxF);
+        hipMalloc((void **) &b->d_dbgmetric, sizeof(int) * (size_t) b->S * 2 * b->maxF * 2);
+    }
+}
+
+extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
+                                          long long out_stride, int *d_out_bytes, void *stream)
+{
+    if (!b || nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range"); return -1; }
+    hipStream_t q = (hipStream_t) stream;
+    HIPCHK(hipSetDevice(b->device));
+    const int S = b->S, NG = 2 * nframes;
+    const long long nsamp = 1152LL * nframes;
+    // The subband carry sits in slots NG_prev..NG_prev+2 only if the previous call used another
+    // frame count; k_carry always rolls it to slots 0..2, so nothing to do here.
+    dim3 g1(S * 2, (NG + K1_GPB - 1) / K1_GPB);
+    const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
+    hipLaunchKernelGGL(k_polyphase, g1, dim3(256), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG);
+    int tot = S * 2 * NG * 9;
+    hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot);
+    tot = S * NG;
+    hipLaunchKernelGGL(k_attack_flg, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
+                       b->debug ? b->d_dbgmetric : nullptr, NG, tot);
+    hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, b->d_bt, NG, S, b->d_status);
+    long long units = (long long) S * NG * 2;
+    hipLaunchKernelGGL(k_mdct, dim3((unsigned) ((units + 1) / 2)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_bt, b->d_xr, NG, SG, units);
+    hipLaunchKernelGGL(k_psy, dim3((unsigned) units), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_etab, b->d_thr, NG);
+    hipLaunchKernelGGL(k_msmetric, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_msbase, NG);
+    AllocArgs a;
+    a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
+    a.msbase = b->d_msbase; a.bt = b->d_bt; a.out = d_out; a.out_bytes = d_out_bytes;
+    a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, q));
+    hipLaunchKernelGGL(k_alloc, dim3(S), dim3(64), 0, q, a);
+    HIPCHK(hipEventRecord(e1, q));
+    b->pending.push_back({e0, e1});
+    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S);
+    HIPCHK(hipGetLastError());
+    b->lastNG = NG;
+    return 0;
+}
+
+extern "C" float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls)
+{
+    hipSetDevice(b->device);
+    for (auto &pr : b->pending) {
+        hipEventSynchronize(pr.second);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { b->alloc_ms_sum += ms; b->alloc_calls++; }
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    b->pending.clear();
+    float mean = b->alloc_calls ? (float) (b->alloc_ms_sum / b->alloc_calls) : 0.0f;
+    if (ncalls) *ncalls = b->alloc_calls;
+    b->alloc_ms_sum = 0;
+    b->alloc_calls = 0;
+    return mean;
+}
+
+extern "C" int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out,
+                                        long long out_stride, int *out_bytes)
+{
+    if (!b) return -1;
+    HIPCHK(hipSetDevice(b->device));
+    long long pbytes = (long long) b->S * nframes * 1152 * 2 * sizeof(int16_t), obytes = (long long) b->S * out_stride;
+    if (pbytes > b->pcm_cap) { if (b->d_pcm) hipFree(b->d_pcm); HIPCHK(hipMalloc((void **) &b->d_pcm, pbytes)); b->pcm_cap = pbytes; }
+    if (obytes > b->out_cap) { if (b->d_out) hipFree(b->d_out); HIPCHK(hipMalloc((void **) &b->d_out, obytes)); b->out_cap = obytes; }
+    HIPCHK(hipMemcpy(b->d_pcm, pcm, pbytes, hipMemcpyHostToDevice));
+    int r = hx_batch_encode_s16_device(b, b->d_pcm, nframes, b->d_out, out_stride, b->d_outbytes, nullptr);
+    if (r) return r;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_bytes, b->d_outbytes, sizeof(int) * b->S, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, b->d_out, obytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int hx_batch_status(hx_batch *b)
+{
+    int v = -1;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost);
+    return v;
+}
+
+extern "C" HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int i)
+{
+    HX_INT_PAIR r = {0, 0};
+    if (!b || i < 0 || i >= b->S) return r;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    unsigned v[2];
+    hipMemcpy(&v[0], (char *) (b->d_st + i) + offsetof(HxStream, tot_frames_out), 4, hipMemcpyDeviceToHost);
+    hipMemcpy(&v[1], (char *) (b->d_st + i) + offsetof(HxStream, tot_bytes_out), 4, hipMemcpyDeviceToHost);
+    r.a = (int) v[0]; r.b = (int) v[1];
+    return r;
+}
+
+extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *dst, long long cap)
+{
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    const long long S = b->S, NG = b->lastNG;
+    const void *src = nullptr;
+    long long n = 0;
+    std::string k(name);
+    if (k == "sb") { src = b->d_sb; n = sizeof(float) * S * 2 * (2LL * b->maxF + 3) * 576; }
+    else if (k == "xr") { src = b->d_xr; n = sizeof(float) * S * NG * 1152; }
+    else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }
+    else if (k == "thr") { src = b->d_thr; n = sizeof(float) * S * NG * 128; }
+    else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }
+    else if (k == "bt") { src = b->d_bt; n = S * NG; }
+    else if (k == "eng") { src = b->d_eng; n = sizeof(int) * S * 2 * NG * 9; }
+    else if (k == "dbg" && b->d_dbg) { src = b->d_dbg; n = sizeof(HxFrameDebug) * S * (NG / 2); }
+    else if (k == "state") { src = b->d_st; n = sizeof(HxStream) * S; }
+    else if (k == "attack" && b->d_dbgmetric) { src = b->d_dbgmetric; n = sizeof(int) * S * NG * 2; }
+    if (!src) return -1;
+    if (n > cap) n = cap;
+    hipMemcpy(dst, src, (size_t) n, hipMemcpyDeviceToHost);
+    return n;
+}
+
+// host-side table generation exposed for the CPU tests (no GPU needed): resolves `ec` and copies
+// the named table; returns bytes copied, 0 if the configuration is rejected, -1 for a bad name
+extern "C" long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *name, void *dst, long long cap)
+{
+    static HxParams p;
+    static HxGlobalTabs g;
+    if (!hx_resolve((const HxControl *) ec, &p)) return 0;
+    hx_global_tabs(&g);
+    std::string k(name);
+    const void *src = nullptr;
+    long long n = 0;
+#define TAB(nm, obj) else if (k == nm) { src = &(obj); n = sizeof(obj); }
+    if (k == "psy_w") { src = p.psyL.w; n = sizeof(p.psyL.w); }
+    TAB("psy_cnt", p.psyL.cnt) TAB("psy_off", p.psyL.off) TAB("psy_nsum", p.psyL.nsum) TAB("psy_npart", p.psyL.npart)
+    TAB("dct_coef", p.dct_coef) TAB("win", p.win) TAB("csa", p.csa) TAB("m18_w", p.m18_w) TAB("m18_w2", p.m18_w2) TAB("m18_c", p.m18_c)
+    TAB("look_gain", p.look_gain) TAB("look_34igain", p.look_34igain) TAB("look_ix43", p.look_ix43)
+    TAB("look_log_cbwmb", p.look_log_cbwmb) TAB("nBand_l", p.nBand_l) TAB("startBand_l", p.startBand_l)
+    TAB("nsf", p.nsf) TAB("taperNT", p.taperNT) TAB("head", p.head) TAB("ec", p.ec)
+    TAB("anwin", g.anwin) TAB("mblog", g.mblog) TAB("mbexp_lo", g.mbexp_lo) TAB("mbexp_hi", g.mbexp_hi)
+    TAB("pow34_exp", g.pow34_exp) TAB("quant_off", g.quant_off) TAB("logsub", g.logsub)
+    TAB("huff_code", g.huff_code) TAB("huff_len", g.huff_len)
+#undef TAB
+    if (k == "scalars") {
+        static int v[16];
+        v[0] = p.nsb_limit; v[1] = p.nsb_ms0; v[2] = p.band_limit; v[3] = p.main_framebytes; v[4] = p.AveTargetBits;
+        v[5] = p.initialMNR; v[6] = p.ms_flag; v[7] = p.hf_flag; v[8] = p.vbr_flag; v[9] = p.framebytes;
+        v[10] = p.remainder; v[11] = p.ivbr_max; v[12] = p.vbr_pool_target; v[13] = p.samprate; v[14] = p.totbitrate; v[15] = p.nsb_ms1;
+        src = v; n = sizeof(v);
+    }
+    if (!src) return -1;
+    if (n > cap) n = cap;
+    memcpy(dst, src, (size_t) n);
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// CMp3Enc-compatible single-stream encoder: a batch of one, one frame per call.
+struct hx_enc {
+    int device = 0;
+    hx_batch *b = nullptr;
+    HxParams p;
+    int src_bits = 0, src_float = 0;
+    std::vector<int16_t> pcm16;
+    std::vector<unsigned char> outbuf;
+    unsigned frames = 0, bytes = 0;
+    int ave = 0;
+};
+
+extern "C" hx_enc *hx_enc_create(int device)
+{
+    hx_enc *e = new hx_enc;
+    e->device = device;
+    return e;
+}
+
+extern "C" void hx_enc_destroy(hx_enc *e)
+{
+    if (!e) return;
+    hx_batch_destroy(e->b);
+    delete e;
+}
+
+extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
+{
+    if (e->b) { hx_batch_destroy(e->b); e->b = nullptr; }       // re-init is legal (mp3enc.cpp:267-272)
+    int r = hx_resolve((const HxControl *) ec, &e->p);
+    if (!r) { set_err("configuration rejected"); return 0; }
+    e->b = hx_batch_create(e->device, 1, ec, 1, 1);
+    if (!e->b) return 0;
+    e->frames = e->bytes = 0; e->ave = 0;
+    e->pcm16.assign(2304, 0);
+    e->outbuf.assign((size_t) hx_batch_out_stride(e->b, 1) + 65536, 0);
+    e->src_bits = 0;
+    return r;
+}
+
+static HX_IN_OUT encode_one(hx_enc *e, const int16_t *pcm, unsigned char *bs_out, int in_bytes)
+{
+    HX_IN_OUT x = {in_bytes, 0};
+    int nb = 0;
+    long long stride = (long long) e->outbuf.size();
+    if (hx_batch_encode_s16_host(e->b, pcm, 1, e->outbuf.data(), stride, &nb) == 0) {
+        memcpy(bs_out, e->outbuf.data(), nb);
+        x.out_bytes = nb;
+        e->bytes += nb;
+        e->ave = e->ave + ((((nb << 8) - e->ave)) >> 7);
+        e->frames = (unsigned) hx_batch_frames_bytes(e->b, 0).a;
+    }
+    return x;
+}
+
+extern "C" HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out)
+{
+    // the GPU path ingests 16-bit PCM; the float entry point takes float at int16 scale
+    // (pub/mp3enc.h:90-98), which is exact for integral values in range (the CLI's 16-bit case)
+    for (int i = 0; i < 2304; i++) {
+        float v = pcm[i];
+        if (v > 32767.0f) v = 32767.0f;
+        if (v < -32768.0f) v = -32768.0f;
+        e->pcm16[i] = (int16_t) v;
+    }
+    return encode_one(e, e->pcm16.data(), bs_out, 9216);
+}
+
+extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, int source_bits, int source_is_float,
+                                            int mpeg_select, int mono_convert)
+{
+    (void) mpeg_select;
+    if (mono_convert || ec->mode == 3) { set_err("mono is not on the GPU path"); return 0; }
+    if (!(source_bits == 16 || (source_bits == 32 && source_is_float))) { set_err("16-bit or float sources only"); return 0; }
+    if (ec->samprate != 32000 && ec->samprate != 44100 && ec->samprate != 48000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
+    int r = hx_enc_L3_audio_encode_init(e, ec);
+    if (!r) return 0;
+    e->src_bits = source_bits;
+    e->src_float = source_is_float;
+    return source_bits == 16 ? 4608 : 9216;
+}
+
+extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out)
+{
+    if (e->src_bits == 16) return encode_one(e, (const int16_t *) pcm, bs_out, 4608);
+    if (e->src_bits == 32) {    // float in [-1, 1) is scaled by 32768 (srcc.cpp:805-808)
+        std::vector<float> t(2304);
+        const float *f = (const float *) pcm;
+        for (int i = 0; i < 2304; i++) t[i] = f[i] * 32768.0f;
+        return hx_enc_L3_audio_encode(e, t.data(), bs_out);
+    }
+    return hx_enc_L3_audio_encode(e, (const float *) pcm, bs_out);
+}
+
+extern "C" unsigned hx_enc_get_frames(hx_enc *e) { return e->frames; }
+extern "C" HX_INT_PAIR hx_enc_get_frames_bytes(hx_enc *e) { HX_INT_PAIR r = {(int) e->frames, (int) e->bytes}; return r; }
+extern "C" float hx_enc_get_bitrate_float(hx_enc *e)
+{
+    if (e->frames <= 0) return 0.0f;
+    return ((0.001f * 8.0f) * e->bytes * e->p.samprate / (1152.0f * e->frames));
+}
+extern "C" int hx_enc_get_bitrate(hx_enc *e) { return (int) (hx_enc_get_bitrate_float(e) + 0.5f); }
+extern "C" float hx_enc_get_bitrate2_float(hx_enc *e)
+{
+    if (e->frames <= 0) return 0.0f;
+    return (float) ((0.001f * 8.0f / (1152.0 * 256.0)) * e->ave * e->p.samprate);
+}
+extern "C" void hx_enc_info_ec(hx_enc *e, HX_E_CONTROL *ec) { memcpy(ec, &e->p.ec, sizeof(HxControl)); }
+extern "C" void hx_enc_info_head(hx_enc *e, HX_MPEG_HEAD *h) { memcpy(h, &e->p.head_info, sizeof(HxMpegHead)); }
+extern "C" void hx_enc_info_string(hx_enc *e, char *s)
+{
+    static const char *mode_msg[4] = {"stereo", "joint stereo", "dual", "mono"};
+    const HxControl *ec = &e->p.ec;
+    s += sprintf(s, "Layer III   %s ", mode_msg[e->p.h_mode & 3]);
+    s += sprintf(s, "  %ldHz ", (long) e->p.samprate);
+    if (ec->vbr_flag == 0) s += sprintf(s, "  %dkbps ", e->p.totbitrate);
+    else {
+        s += sprintf(s, " VBR-%d", ec->vbr_mnr);
+        if (ec->vbr_delta_mnr) s += sprintf(s, "(%d)", ec->vbr_delta_mnr);
+    }
+    if (ec->hf_flag) { s += sprintf(s, "  hf"); if (ec->hf_flag & 2) s += sprintf(s, "2"); }
+}

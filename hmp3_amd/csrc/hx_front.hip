@@ -1,0 +1,453 @@
+// hx_front.hip - front-end kernels of the batched MP3 encoder for MI355X (gfx950):
+//   k_polyphase  K1  int16 PCM -> 32 x 18 subband samples per granule   (replaces sbt.c:57-310)
+//   k_attack_eng K2a subband energies in mB for the transient detector  (detect.c:80-101)
+//   k_attack_flg K2b attack metric for both "previous granule short" cases (detect.c:103-141)
+//   k_blocktype  K2c per-stream block-type state machine                (mp3enc.cpp:1398-1440)
+//   k_mdct       K3  window + 18-point MDCT + alias butterflies         (hwin.c:147-322, emdct.c:104-188)
+//   k_psy        K4  partition energies, spreading, unclamped thresholds (emap.c:96, spdsmr.c:188-273)
+//   k_msmetric   K5  L/R vs M/S energy-compaction metric per granule     (bitallo3.cpp:682-742)
+//   k_carry      K8  roll the 3-granule subband carry and the PCM history
+// Parallel over streams x channels x granules (x slots / subbands / partitions).  Each lane
+// evaluates its unit with the reference's operation order, so results are bit-identical.
+#include "hx_dev.h"
+
+#define K1_GPB 14                       // granules per workgroup (252 of 256 lanes busy)
+#define K1_NS (480 + 576 * K1_GPB)      // staged samples
+#define K1_LDS (K1_NS + (K1_NS >> 5) + 1)
+
+template <int M, int N>
+__device__ __forceinline__ void dct_split(const float *x, float *f)
+{
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int blk = 0; blk < M; blk++) {
+        const float *xx = x + blk * N;
+        float *ff = f + blk * N;
+        ff[H + H - 1] = xx[N - 1];
+        ff[H - 1] = xx[N - 2];
+#pragma unroll
+        for (int i = H - 2; i >= 0; i--) {
+            ff[H + i] = xx[2 * i + 1] - ff[H + i + 1];
+            ff[i] = xx[2 * i];
+        }
+    }
+}
+
+template <int M, int N>
+__device__ __forceinline__ void dct_bfly(const float *x, float *f, const float *c)
+{
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int blk = 0; blk < M; blk++) {
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            float tmp = c[j] * x[blk * N + j + H];
+            float t = x[blk * N + j];
+            f[blk * N + j] = t + tmp;
+            f[blk * N + N - 1 - j] = t - tmp;
+        }
+    }
+}
+
+// One lane = one time slot: 512-tap window folded to 32 values, then the 32-point DCT.
+__global__ __launch_bounds__(256) void k_polyphase(const int16_t *__restrict__ pcm, long long nsamp,
+                                                   const HxStream *__restrict__ st,
+                                                   const HxParams *__restrict__ prm,
+                                                   const HxGlobalTabs *__restrict__ gt,
+                                                   float *__restrict__ sb, int NG, int SG)
+{
+    __shared__ float xs[K1_LDS];
+    const int s = blockIdx.x >> 1, ch = blockIdx.x & 1;
+    const int g0 = blockIdx.y * K1_GPB;
+    const int ng = min(K1_GPB, NG - g0);
+    const int count = 480 + 576 * ng;
+    const HxStream *ss = st + s;
+    const HxParams *p = prm + ss->cls;
+    const int16_t *src = pcm + (long long) s * nsamp * 2 + ch;
+    for (int idx = threadIdx.x; idx < count; idx += 256) {
+        int n = 576 * g0 - 480 + idx;
+        float v = (n < 0) ? ss->pcm_hist[ch][480 + n] : (float) src[2 * (long long) n];
+        xs[idx + (idx >> 5)] = v;
+    }
+    __syncthreads();
+    const int gl = threadIdx.x / 18, t = threadIdx.x - gl * 18;
+    if (gl >= ng) return;
+    const int base = 480 + 576 * gl + 32 * t + 31;          // newest sample of the slot
+    const float *P = xs + (base + (base >> 5) - 526);       // P[526 - pad(off)] = sample of age off
+    const float *W = gt->anwin;
+#define XS(off) P[526 - ((off) + ((off) >> 5))]
+    float a[32], b[32];
+    {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s1 += W[16 + 64 * j] * XS(16 + 64 * j);
+        b[0] = s1;
+    }
+#pragma unroll
+    for (int k = 1; k < 32; k++) {
+        const int A = (k <= 16) ? 16 + k : 80 - k;
+        const int B = (k <= 16) ? 16 - k : 16 + k;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            s1 += W[A + 64 * j] * XS(A + 64 * j);
+            s2 += W[B + 64 * j] * XS(B + 64 * j);
+        }
+        b[k] = s1 + s2;
+    }
+#undef XS
+    const float *c = p->dct_coef;
+    dct_split<1, 32>(b, a);
+    dct_split<2, 16>(a, b);
+    dct_split<4, 8>(b, a);
+    dct_split<8, 4>(a, b);
+    dct_bfly<16, 2>(b, a, c + 30);
+    dct_bfly<8, 4>(a, b, c + 28);
+    dct_bfly<4, 8>(b, a, c + 24);
+    dct_bfly<2, 16>(a, b, c + 16);
+    float *out = sb + ((long long) (s * 2 + ch) * SG + (g0 + gl + 3)) * 576 + t;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        float tmp = c[k] * b[k + 16];
+        out[18 * k] = b[k] + tmp;
+        out[18 * (31 - k)] = b[k] - tmp;
+    }
+}
+
+// energies of subbands 4..17 per slot pair, as mB.  eng index g <-> subband slot g + 2.
+__global__ void k_attack_eng(const float *__restrict__ sb, const HxGlobalTabs *__restrict__ gt,
+                             int *__restrict__ eng, int NG, int SG, int total)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    int k = id % 9, r = id / 9;
+    int g = r % NG, sc = r / NG;
+    const float *y = sb + ((long long) sc * SG + (g + 2)) * 576 + 18 * 4 + 2 * k;
+    float sum = 7.0e4f;
+    for (int i = 0; i < 14; i++, y += 18) {
+        float x = y[0] * y[0]; sum += x;
+        x = y[1] * y[1]; sum += x;
+    }
+    eng[id] = hx_mblog(gt->mblog, sum);
+}
+
+// attack metric of one channel at coded step g, for short_flag_prev = 0 and 1
+__device__ __forceinline__ void attack_metric(const int *hist, const int *eng, int g, int *m0, int *m1)
+{
+    // virtual buffer A: 32 history values followed by 9 new values per step
+    int w[32];
+#pragma unroll
+    for (int j = 10; j < 29; j++) {
+        int a = 9 * (g + 1) + j;
+        w[j] = (a < 32) ? hist[a] : eng[a - 32];
+    }
+    int r0 = 0, r1 = 0;
+#pragma unroll
+    for (int j = 17; j < 29; j++) {
+        int a0 = max(w[j - 6], w[j - 7]);
+        int a1 = max(w[j - 4], w[j - 5]);
+        int a2 = max(w[j - 2], w[j - 3]);
+        a1 = max(a1, a0);
+        int a = max(a1, a2);
+        int d = w[j] - a;
+        r0 = max(r0, d);
+        if (j >= 18) r1 = max(r1, d);
+    }
+    *m0 = r0;
+    *m1 = r1;
+}
+
+__global__ void k_attack_flg(const HxStream *__restrict__ st, const HxParams *__restrict__ prm,
+                             const int *__restrict__ eng, unsigned char *__restrict__ flg,
+                             int *__restrict__ dbg_metric, int NG, int total)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    int g = id % NG, s = id / NG;
+    const HxStream *ss = st + s;
+    int thr = prm[ss->cls].short_block_threshold;
+    int a0, a1, b0, b1;
+    attack_metric(ss->attack_hist[0], eng + (long long) (s * 2 + 0) * NG * 9, g, &a0, &a1);
+    attack_metric(ss->attack_hist[1], eng + (long long) (s * 2 + 1) * NG * 9, g, &b0, &b1);
+    int f0 = (a0 > thr) | (b0 > thr), f1 = (a1 > thr) | (b1 > thr);
+    flg[id] = (unsigned char) (f0 | (f1 << 1));
+    if (dbg_metric) { dbg_metric[id * 2] = a0; dbg_metric[id * 2 + 1] = b0; }
+}
+
+// serial per stream: block_type[g] = table[prev type][short now][short next]
+__global__ void k_blocktype(HxStream *__restrict__ st, const unsigned char *__restrict__ flg,
+                            const int *__restrict__ eng, unsigned char *__restrict__ bt, int NG, int S,
+                            int *__restrict__ status)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const unsigned char sel[16] = {0, 1, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 0, 1, 2, 2};
+    HxStream *ss = st + s;
+    int prev_next = ss->short_flag_next_prev, prev_bt = ss->bt_prev;
+    for (int g = 0; g < NG; g++) {
+        int f = flg[(long long) s * NG + g];
+        int next = prev_next ? (f >> 1) & 1 : f & 1;
+        int cur = prev_next;
+        int b = sel[prev_bt * 4 + cur * 2 + next];
+        bt[(long long) s * NG + g] = (unsigned char) b;
+        if (b == 2) atomicOr(status, 1);        // short blocks: not on the GPU path yet
+        prev_bt = b;
+        prev_next = next;
+    }
+    ss->short_flag_next_prev = prev_next;
+    ss->bt_prev = prev_bt;
+    // roll the energy history: last 32 values of [hist | eng]
+    for (int c = 0; c < 2; c++) {
+        int tmp[32];
+        const int *e = eng + (long long) (s * 2 + c) * NG * 9;
+        for (int j = 0; j < 32; j++) {
+            int a = 9 * NG + j;
+            tmp[j] = (a < 32) ? ss->attack_hist[c][a] : e[a - 32];
+        }
+        for (int j = 0; j < 32; j++) ss->attack_hist[c][j] = tmp[j];
+    }
+}
+
+// 18-point transform of the folded, windowed input (reference emdct.c:104-188)
+__device__ __forceinline__ void mdct18(const HxParams *p, const float *f, float *y)
+{
+    const float *w = p->m18_w, *w2 = p->m18_w2;
+    const float (*c)[4] = p->m18_c;
+    float a[9], b[9], g1, g2, ap, bp, a8p, b8p;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        g1 = w[q] * f[q];
+        g2 = w[17 - q] * f[17 - q];
+        ap = g1 + g2;
+        bp = w2[q] * (g1 - g2);
+        g1 = w[8 - q] * f[8 - q];
+        g2 = w[9 + q] * f[9 + q];
+        a8p = g1 + g2;
+        b8p = w2[8 - q] * (g1 - g2);
+        a[q] = ap + a8p;
+        a[5 + q] = ap - a8p;
+        b[q] = bp + b8p;
+        b[5 + q] = bp - b8p;
+    }
+    g1 = w[4] * f[4];
+    g2 = w[13] * f[13];
+    a[4] = g1 + g2;
+    b[4] = w2[4] * (g1 - g2);
+    y[0] = 0.5f * (a[0] + a[1] + a[2] + a[3] + a[4]);
+    y[1] = 0.5f * (b[0] + b[1] + b[2] + b[3] + b[4]);
+    y[2] = c[1][0] * a[5] + c[1][1] * a[6] + c[1][2] * a[7] + c[1][3] * a[8];
+    y[3] = c[1][0] * b[5] + c[1][1] * b[6] + c[1][2] * b[7] + c[1][3] * b[8] - y[1];
+    y[1] = y[1] - y[0];
+    y[2] = y[2] - y[1];
+    y[4] = c[2][0] * a[0] + c[2][1] * a[1] + c[2][2] * a[2] + c[2][3] * a[3] - a[4];
+    y[5] = c[2][0] * b[0] + c[2][1] * b[1] + c[2][2] * b[2] + c[2][3] * b[3] - b[4] - y[3];
+    y[3] = y[3] - y[2];
+    y[4] = y[4] - y[3];
+    y[6] = c[3][0] * (a[5] - a[7] - a[8]);
+    y[7] = c[3][0] * (b[5] - b[7] - b[8]) - y[5];
+    y[5] = y[5] - y[4];
+    y[6] = y[6] - y[5];
+    y[8] = c[4][0] * a[0] + c[4][1] * a[1] + c[4][2] * a[2] + c[4][3] * a[3] + a[4];
+    y[9] = c[4][0] * b[0] + c[4][1] * b[1] + c[4][2] * b[2] + c[4][3] * b[3] + b[4] - y[7];
+    y[7] = y[7] - y[6];
+    y[8] = y[8] - y[7];
+    y[10] = c[5][0] * a[5] + c[5][1] * a[6] + c[5][2] * a[7] + c[5][3] * a[8];
+    y[11] = c[5][0] * b[5] + c[5][1] * b[6] + c[5][2] * b[7] + c[5][3] * b[8] - y[9];
+    y[9] = y[9] - y[8];
+    y[10] = y[10] - y[9];
+    y[12] = 0.5f * (a[0] + a[2] + a[3]) - a[1] - a[4];
+    y[13] = 0.5f * (b[0] + b[2] + b[3]) - b[1] - b[4] - y[11];
+    y[11] = y[11] - y[10];
+    y[12] = y[12] - y[11];
+    y[14] = c[7][0] * a[5] + c[7][1] * a[6] + c[7][2] * a[7] + c[7][3] * a[8];
+    y[15] = c[7][0] * b[5] + c[7][1] * b[6] + c[7][2] * b[7] + c[7][3] * b[8] - y[13];
+    y[13] = y[13] - y[12];
+    y[14] = y[14] - y[13];
+    y[16] = c[8][0] * a[0] + c[8][1] * a[1] + c[8][2] * a[2] + c[8][3] * a[3] + a[4];
+    y[17] = c[8][0] * b[0] + c[8][1] * b[1] + c[8][2] * b[2] + c[8][3] * b[3] + b[4] - y[15];
+    y[15] = y[15] - y[14];
+    y[16] = y[16] - y[15];
+    y[17] = y[17] - y[16];
+}
+
+// One lane = one subband of one (stream, channel, granule); 2 granule-channels per wave.
+// Frequency inversion (hwin.c:282) is applied while reading, so the stored subband samples
+// stay un-inverted; the alias butterflies exchange 8 values with each neighbour lane.
+__global__ __launch_bounds__(64) void k_mdct(const float *__restrict__ sb, const HxStream *__restrict__ st,
+                                             const HxParams *__restrict__ prm,
+                                             const unsigned char *__restrict__ bt,
+                                             float *__restrict__ xr, int NG, int SG, long long units)
+{
+    const int lane = threadIdx.x, sbnd = lane & 31;
+    long long u = (long long) blockIdx.x * 2 + (lane >> 5);   // unit = (s, g, ch)
+    bool live = u < units;
+    if (!live) u = units - 1;
+    const int ch = (int) (u & 1);
+    const long long sg = u >> 1;
+    const int g = (int) (sg % NG), s = (int) (sg / NG);
+    const HxParams *p = prm + st[s].cls;
+    const int nsb = p->nsb_ms0;
+    const int btype = bt[(long long) s * NG + g];
+    const float *x1 = sb + ((long long) (s * 2 + ch) * SG + g) * 576 + sbnd * 18;     // S[g-3]
+    const float *x2 = x1 + 576;                                                             // S[g-2]
+    float y[18], f[18];
+    const bool act = sbnd < nsb;
+    if (act) {
+        float p1[18], p2[18];
+        const bool inv = (sbnd & 1) != 0;       // odd subbands: negate odd time slots
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+            float a = x1[i], b = x2[i];
+            if (inv && (i & 1)) { a = -a; b = -b; }
+            p1[i] = a; p2[i] = b;
+        }
+        const float *w = p->win[btype == 2 ? 0 : btype];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            f[j] = w[26 - j] * p2[8 - j] + w[27 + j] * p2[9 + j];
+            f[9 + j] = w[j] * p1[j] + w[17 - j] * p1[17 - j];
+        }
+        mdct18(p, f, y);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 18; i++) y[i] = 0.0f;
+    }
+    // alias reduction between subband k (lane) and k+1: x[17-i] with next lane's x[i]
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float up = __shfl_down(y[i], 1, 64);            // next subband's element i
+        float dn = __shfl_up(y[17 - i], 1, 64);         // previous subband's element 17-i
+        float cs = p->csa[0][i], ca = p->csa[1][i];
+        float a = y[17 - i], b = y[i];
+        float na = a, nb = b;
+        if (sbnd < nsb - 1) na = a * cs + up * ca;      // upper edge of this band
+        else if (sbnd == nsb - 1) na = a * cs;          // last coded band: half butterfly
+        if (sbnd >= 1 && sbnd < nsb) nb = b * cs - dn * ca;     // lower edge (pairs with band-1)
+        y[17 - i] = na;
+        y[i] = nb;
+    }
+    if (live) {
+        float *o = xr + ((sg * 2 + ch) * 576) + sbnd * 18;
+#pragma unroll
+        for (int i = 0; i < 18; i++) o[i] = y[i];
+    }
+}
+
+// Psychoacoustic model, long blocks: one wave per (stream, granule, channel); lane = partition.
+// Outputs etab (energy + absolute threshold) and thr = a * stab (threshold before pre-echo control).
+__global__ __launch_bounds__(64) void k_psy(const float *__restrict__ xr, const HxStream *__restrict__ st,
+                                            const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
+                                            float *__restrict__ etab_out, float *__restrict__ thr_out, int NG)
+{
+    __shared__ float xtab[64];
+    const int lane = threadIdx.x;
+    const long long u = blockIdx.x;             // (s, g, ch)
+    const int s = (int) ((u >> 1) / NG);
+    const HxParams *p = prm + st[s].cls;
+    const HxPsyTab *pt = &p->psyL;
+    const float *x = xr + u * 576;
+    const float *w = pt->w;
+    const float alpha = 0.30f;
+    const int npart = pt->npart, npart2 = (npart + 1) & (~1);
+    float e = 0.0f;
+    if (lane < pt->npart_e) {
+        int i0 = pt->pstart[lane], n = pt->nsum[lane];
+        float sum = 0.0f;
+        for (int k = 0; k < n; k++) sum += x[i0 + k] * x[i0 + k];
+        e = sum;
+    }
+    float et = 0.0f;
+    int mbe = 0;
+    if (lane < npart2) {
+        et = w[lane] + e;
+        mbe = hx_mblog(gt->mblog, et);
+        xtab[lane] = hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, (int) (alpha * mbe));
+    }
+    __syncthreads();
+    float stab = 0.0f;
+    int snr = 0;
+    if (lane < npart) {
+        float sacc = 0.1f;
+        int q = pt->off[lane], n = pt->cnt[lane], r = pt->row[lane];
+        for (int j = 0; j < n; j++) sacc += w[r + j] * xtab[q + j];
+        sacc = (0.03f * 0.1f * 0.35f) * hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, (int) ((1.0f / alpha) * hx_mblog(gt->mblog, sacc))) + w[lane];
+        stab = sacc;
+        snr = mbe - hx_mblog(gt->mblog, w[lane] + sacc);
+    }
+    int prev = __shfl_up(snr, 1, 64);
+    if (lane == 0) prev = 0;
+    const bool in = lane < npart;
+    int nsnr = hx_wave_sum((in && snr > 0) ? 1 : 0);
+    int totsnr = hx_wave_sum(in ? max(-200, snr) : 0);
+    int snrvar = hx_wave_sum(in ? abs(snr - prev) : 0);
+    int d = 0;
+    if (nsnr > 0) {
+        int d0 = hx_round(1.3f * (totsnr / npart) - 850);
+        int itmp = snrvar / npart;
+        int dv = min(500 - itmp, 0);
+        d = d0 + dv;
+        d = max(d, -2000);
+        d = min(d, 600);
+    }
+    d += 300;
+    int dm0 = (300 - d) >> 4;
+    int m = lane >> 1;
+    int dm = max(dm0 * max(m - 13, 0), 0);
+    float a = hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, d + dm);
+    etab_out[u * 64 + lane] = (lane < npart2) ? et : 0.0f;
+    thr_out[u * 64 + lane] = (lane < npart2) ? a * stab : 0.0f;
+}
+
+// M/S decision metric before hysteresis: lane = scalefactor band (reference bitallo3.cpp:695-742)
+__global__ __launch_bounds__(64) void k_msmetric(const float *__restrict__ xr, const HxStream *__restrict__ st,
+                                                 const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
+                                                 int *__restrict__ msbase, int NG)
+{
+    const int lane = threadIdx.x;
+    const long long sg = blockIdx.x;            // (s, g)
+    const int s = (int) (sg / NG);
+    const HxParams *p = prm + st[s].cls;
+    const float *x0 = xr + sg * 1152, *x1 = x0 + 576;
+    int v = 0;
+    if (lane < p->nsf[0]) {
+        int k = p->startBand_l[lane], n = p->nBand_l[lane];
+        float el = 100.0f, er = 100.0f, t = 0.0f;
+        for (int j = 0; j < n; j++, k++) {
+            float a = x0[k] * x0[k], b = x1[k] * x1[k], c = x0[k] * x1[k];
+            el += a; er += b; t += c;
+        }
+        float es, ed;
+        es = ed = el + er;
+        t = t + t;
+        es = es + t;
+        ed = ed - t;
+        int mblr = hx_mblog(gt->mblog, el + er) - hx_mblog(gt->mblog, el > er ? el : er);
+        int mbsd = hx_mblog(gt->mblog, es + ed) - hx_mblog(gt->mblog, es > ed ? es : ed);
+        int psd = max(75 - abs(mblr - 120), 0);
+        mbsd = min(mbsd, (mbsd >> 1) + 120);
+        mbsd += psd;
+        v = n * (mblr - mbsd);
+    }
+    v = hx_wave_sum(v);
+    if (lane == 0) msbase[sg] = v;
+}
+
+// After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
+// last 480 input samples into the stream state.
+__global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const int16_t *__restrict__ pcm,
+                        long long nsamp, int NG, int SG, int S)
+{
+    const int sc = blockIdx.x;                  // s*2 + ch
+    const int s = sc >> 1, ch = sc & 1;
+    float *base = sb + (long long) sc * SG * 576;
+    for (int e = threadIdx.x; e < 576; e += blockDim.x)
+        for (int k = 0; k < 3; k++) base[k * 576 + e] = base[(NG + k) * 576 + e];
+    HxStream *ss = st + s;
+    const int16_t *src = pcm + (long long) s * nsamp * 2 + ch;
+    for (int i = threadIdx.x; i < 480; i += blockDim.x) {
+        long long n = nsamp - 480 + i;
+        // fewer than 480 new samples never happens (a frame is 1152), so all come from this batch
+        ss->pcm_hist[ch][i] = (float) src[2 * n];
+    }
+    if (threadIdx.x == 0 && ch == 0) ss->frames_in += (int) (nsamp / 1152);
+}

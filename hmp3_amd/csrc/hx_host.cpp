@@ -1,0 +1,408 @@
+// hx_host.cpp - host side of the MI355X batched MP3 encoder: resolves an E_CONTROL into the
+// per-class parameter/table block the kernels consume.  Mirrors the behaviour of
+// CMp3Enc::L3_audio_encode_init (reference mp3enc.cpp:220-870), setup_header (setup.c:189),
+// CBitAllo3::BitAlloInit (bitallo3.cpp:288), L3table_init (l3init.c:176) and amod_initLong
+// (amodini2.c:743).  Table values are generated with the same double-precision libm
+// expressions the reference uses so that the float casts agree bit for bit.
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include "hx_types.h"
+#include "hx_host.h"
+#include "iso_data.inc"
+
+#define MX(a, b) ((a) > (b) ? (a) : (b))
+#define MN(a, b) ((a) < (b) ? (a) : (b))
+
+static float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// ISO 11172-3 Table B.8, MPEG-1 (44.1, 48, 32 kHz)
+static const short sfb_long[3][23] = {
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 52, 62, 74, 90, 110, 134, 162, 196, 238, 288, 342, 418, 576},
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 42, 50, 60, 72, 88, 106, 128, 156, 190, 230, 276, 330, 384, 576},
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 54, 66, 82, 102, 126, 156, 194, 240, 296, 364, 448, 550, 576}};
+static const short sfb_short[3][14] = {
+    {0, 4, 8, 12, 16, 22, 30, 40, 52, 66, 84, 106, 136, 192},
+    {0, 4, 8, 12, 16, 22, 28, 38, 50, 64, 80, 100, 126, 192},
+    {0, 4, 8, 12, 16, 22, 30, 42, 58, 78, 104, 138, 180, 192}};
+static const int br_mpeg1_l3[16] = {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, -1};
+
+void hx_host_default_control(HxControl *ec)
+{
+    memset(ec, 0, sizeof(*ec));
+    ec->mode = 1; ec->bitrate = -1; ec->samprate = 44100; ec->nsbstereo = -1; ec->filter_select = -1;
+    ec->freq_limit = 24000; ec->nsb_limit = -1; ec->layer = 3; ec->cr_bit = 1; ec->original = 1;
+    ec->vbr_flag = 1; ec->vbr_mnr = 50; ec->vbr_br_limit = 160;
+    ec->chan_add_f0 = ec->chan_add_f1 = 24000; ec->sparse_scale = -1;
+    ec->quick = -1; ec->test1 = -1; ec->short_block_threshold = 700;
+}
+
+void hx_global_tabs(HxGlobalTabs *g)
+{
+    static const double q[32] = {
+        0.09460, 0.02799, 0.01671, 0.01192, 0.00927, 0.00758, 0.00641, 0.00556, 0.00490, 0.00439, 0.00397,
+        0.00362, 0.00333, 0.00309, 0.00287, 0.00269, 0.00253, 0.00238, 0.00225, 0.00214, 0.00203, 0.00194,
+        0.00185, 0.00177, 0.00170, 0.00163, 0.00157, 0.00152, 0.00146, 0.00141, 0.00136, 0.00132};
+    memset(g, 0, sizeof(*g));
+    for (int i = 0; i < 512; i++) g->anwin[i] = bits2f(HX_ANWIN_BITS[i]);
+    for (int i = 0; i < 256; i++) {
+        g->mblog[i] = (int) floor(1000.0 * log10(1.0 + (i + 0.5) / 256.0) + 0.5) - 38227;
+        g->mbexp_lo[i] = (float) pow(10.0, i / 1000.0);
+        g->mbexp_hi[i] = (float) pow(10.0, ((int) (signed char) i) * 256 / 1000.0);
+        g->pow34_exp[i] = (float) pow(2.0, 0.75 * (i - 127));
+    }
+    g->pow34_exp[0] = 0.0f;
+    g->pow34_exp[255] = bits2f(0x7F800000u);
+    for (int i = 0; i < 16; i++) { g->pow34_a[i] = bits2f(HX_POW34_A_BITS[i]); g->pow34_b[i] = bits2f(HX_POW34_B_BITS[i]); }
+    for (int i = 0; i < 32; i++) g->quant_off[i] = (float) q[i] - 0.4375f;
+    for (int i = 0; i < 84; i++) g->logsub[i] = (int) floor(1000.0 * log10(2.0 - pow(10.0, -(16 * i + 8) / 1000.0)));
+    int n = (int) (sizeof(HX_HUFF_CODE) / sizeof(HX_HUFF_CODE[0]));
+    for (int i = 0; i < n; i++) { g->huff_code[i] = HX_HUFF_CODE[i]; g->huff_len[i] = HX_HUFF_LEN[i]; }
+    for (int i = 0; i < 32; i++) { g->huff_off[i] = HX_HUFF_OFF[i]; g->huff_dim[i] = (unsigned char) HX_HUFF_DIM[i]; g->huff_lin[i] = HX_HUFF_LINBITS[i]; }
+    for (int i = 0; i < 16; i++) { g->quada_code[i] = HX_QUADA_CODE[i]; g->quada_len[i] = HX_QUADA_LEN[i]; }
+}
+
+static int sfbl_limit(int sr, int band_limit)
+{
+    int i;
+    for (i = 0; i < 23; i++) if (band_limit <= sfb_long[sr][i]) break;
+    return i > 21 ? 21 : i;
+}
+
+static void transform_tables(HxParams *p)
+{
+    static const float Ci[8] = {-0.6f, -0.535f, -0.33f, -0.185f, -0.095f, -0.041f, -0.0142f, -0.0037f};
+    double pi = 4.0 * atan(1.0), t;
+    int k = 0;
+    for (int n = 16; n >= 1; n /= 2)
+        for (int q = 0; q < n; q++, k++) p->dct_coef[k] = (float) (2.0 * cos((pi / (4 * n)) * (2 * q + 1)));
+    for (int i = 0; i < 8; i++) {
+        float c2 = Ci[i] * Ci[i];
+        p->csa[0][i] = (float) (1.0 / sqrt(1.0 + c2));
+        p->csa[1][i] = (float) (Ci[i] / sqrt(1.0 + c2));
+    }
+    t = pi / 72;
+    for (int q = 0; q < 18; q++) p->m18_w[q] = (float) (2.0 * cos(t * (2 * q + 1)));
+    for (int q = 0; q < 9; q++) p->m18_w2[q] = (float) (2.0 * cos(2 * t * (2 * q + 1)));
+    t = pi / 36;
+    for (int kk = 0; kk < 9; kk++)
+        for (int q = 0; q < 4; q++) p->m18_c[kk][q] = (float) cos(t * (2 * kk) * (2 * q + 1));
+    t = pi / 24;
+    for (int q = 0; q < 6; q++) p->m6_v[q] = (float) (2.0 * cos(t * (2 * q + 1)));
+    for (int q = 0; q < 3; q++) p->m6_v2[q] = (float) (2.0 * cos(2 * t * (2 * q + 1)));
+    t = pi / 12;
+    p->m6_c87 = (float) cos(t * 2 * 1);
+    for (int q = 0; q < 6; q++) p->m6_v[q] = p->m6_v[q] / 2.0f;
+    p->m6_c87 = 2.0f * p->m6_c87;
+    float (*w)[36] = p->win;
+    for (int i = 0; i < 36; i++) w[0][i] = (float) sin(pi / 36 * (i + 0.5));
+    for (int i = 0; i < 18; i++) w[1][i] = (float) sin(pi / 36 * (i + 0.5));
+    for (int i = 18; i < 24; i++) w[1][i] = 1.0f;
+    for (int i = 24; i < 30; i++) w[1][i] = (float) sin(pi / 12 * (i + 0.5 - 18));
+    for (int i = 30; i < 36; i++) w[1][i] = 0.0f;
+    for (int i = 0; i < 6; i++) w[3][i] = 0.0f;
+    for (int i = 6; i < 12; i++) w[3][i] = (float) sin(pi / 12 * (i + 0.5 - 6));
+    for (int i = 12; i < 18; i++) w[3][i] = 1.0f;
+    for (int i = 18; i < 36; i++) w[3][i] = (float) sin(pi / 36 * (i + 0.5));
+    for (int i = 0; i < 12; i++) w[2][i] = (float) sin(pi / 12 * (i + 0.5));
+    for (int i = 12; i < 36; i++) w[2][i] = 0.0f;
+    for (int j = 0; j < 4; j++) { if (j == 2) continue; for (int i = 9; i < 36; i++) w[j][i] = -w[j][i]; }
+    for (int i = 3; i < 12; i++) w[2][i] = -w[2][i];
+    for (int j = 0; j < 4; j++) { if (j == 2) continue; for (int i = 0; i < 36; i++) w[j][i] = (1.0f / 9.0f) * w[j][i]; }
+    for (int i = 0; i < 36; i++) w[2][i] = (1.0f / 3.0f) * w[2][i];
+}
+
+static float f_to_bark(float f)
+{
+    float t = (1.0f / 1000.0f) * f, tt = (1.0f / 7.5f) * t;
+    tt = tt * tt;
+    // double-precision atan on the promoted float arguments, as the C reference does
+    // (in C++ a bare atan(float) would select atanf)
+    return (float) (13.0 * atan((double) (0.76f * t)) + 3.5 * atan((double) tt));
+}
+
+static float interp(const float xy[][2], float x)
+{
+    int i;
+    for (i = 1; i < 100; i++) if (x <= xy[i][0]) break;
+    return xy[i - 1][1] + (x - xy[i - 1][0]) * ((xy[i][1] - xy[i - 1][1])) / (xy[i][0] - xy[i - 1][0]);
+}
+
+// modified Schroeder / Painter-Spanias spreading for long blocks (amodini2.c:203-251)
+static float spread_long(float bz0, float bz)
+{
+    double a = 0.2302585093, x, y, t1 = 1.2, t2 = 1.2, dt;
+    dt = (0.5 / 7.0) * (7.0 - bz0);
+    if (dt < 0.0) dt = 0.0;
+    t1 = t1 + dt; t2 = t2 + dt;
+    dt = bz0 - 22.5;
+    if (dt < 0.0) dt = 0.0;
+    t2 = t2 + dt;
+    x = (bz0 - bz);
+    if (x > 0.0) x = t1 * x; else x = t2 * x;
+    x += 0.474;
+    y = 15.811389 + 7.5 * x - 17.5 * sqrt(1.0 + x * x);
+    if (y <= -60.0) return 0.0f;
+    return (float) exp(y * a);
+}
+
+static void psy_long_tables(HxParams *p)
+{
+    static const float dbsnr[][2] = {
+        {0, 0.0f}, {38, 0.0f}, {115, 0.0f}, {191, 0.0f}, {268, 0.0f}, {345, 0.0f}, {421, 0.0f}, {498, 0.0f},
+        {574, 0.0f}, {651, 1.0f}, {727, 1.0f}, {804, 2.5f}, {880, 2.5f}, {976, 1.5f}, {1091, 1.5f}, {1206, 2.0f},
+        {1321, 2.0f}, {1455, 2.0f}, {1608, 3.0f}, {1761, 3.0f}, {1914, 3.0f}, {2086, 3.0f}, {2278, 3.0f},
+        {2488, 1.0f}, {2718, 1.0f}, {2986, 0.0f}, {3292, 0.0f}, {3637, 0.0f}, {4020, 0.0f}, {4441, 0.0f},
+        {4900, 0.0f}, {5398, 0.0f}, {5934, 0.0f}, {6527, 0.0f}, {7178, 0.0f}, {7905, 0.0f}, {8709, 0.0f},
+        {9589, 0.0f}, {10546, 0.0f}, {11542, 0.0f}, {12575, 0.0f}, {13820, -2.0f}, {15274, -2.0f}, {99999, 0.0f}};
+    static const float absthres[][2] = {
+        {0.0f, 5.0f}, {350.0f, 0.03f}, {2584.0f, 0.01f}, {5857.0f, 0.01f}, {9302.0f, 0.03f},
+        {13092.0f, 0.5f}, {15500.0f, 5.0f}, {99999.0f, 100.0f}};
+    HxPsyTab *pt = &p->psyL;
+    int part[64], t = 0, npart, ntot = 0;
+    float snr_factor[64], bval[64], athres[64], s[64];
+    memset(pt, 0, sizeof(*pt));
+    memset(athres, 0, sizeof(athres));
+    for (int i = 0; i < 64; i++) part[i] = 576;
+    for (int i = 0; i < 22; i++) {      // two partitions per scalefactor band
+        int nb = p->nBand_l_iso[i], m = nb / 2;
+        part[2 * i] = t; t += m;
+        part[2 * i + 1] = t; t += nb - m;
+    }
+    int nbin = 18 * p->nsb_limit;
+    for (npart = 0; npart < 64; npart++) if (part[npart] >= nbin) break;
+    if (npart > 42) npart = 42;
+    float x = 0.5f * p->samprate / 576;
+    int i;
+    for (i = 0; i < 63; i++) {
+        float freq = x * 0.5f * (part[i] + part[i + 1]);
+        snr_factor[i] = (float) pow(10.0, -0.1 * interp(dbsnr, freq));
+        bval[i] = f_to_bark(freq);
+        athres[i] = interp(absthres, freq) * (part[i + 1] - part[i]);
+    }
+    snr_factor[i] = 1.0f;
+    bval[i] = bval[i - 1];
+    float *w = pt->w + 128;
+    for (i = 0; i < npart; i++) {
+        int j, count = 0, nj;
+        for (j = 0; j < 64; j++) s[j] = 0.0f;
+        for (j = 0; j < npart; j++) s[j] = spread_long(bval[i], bval[j]);
+        for (j = 0; j < npart; j++) { if (s[j] > 1.0e-6f) break; s[j] = 0.0f; }
+        for (; j < npart; j++) if (s[j] <= 1.0e-6f) break;
+        for (; j < npart; j++) s[j] = 0.0f;
+        for (j = 0; j < npart; j++) if (s[j] != 0.0f) break;
+        nj = j;
+        if (nj >= npart) break;
+        pt->row[i] = 128 + ntot;
+        for (; j < npart; j++) {
+            if (s[j] == 0.0f) break;
+            count++; ntot++;
+            *w++ = snr_factor[i] * s[j];
+        }
+        pt->cnt[i] = count;
+        pt->off[i] = nj;
+    }
+    pt->npart = i;
+    for (i = 128; i < ntot + 128; i++) if (pt->w[i] > 0.0f) pt->w[i] = (float) pow((double) pt->w[i], 0.30);
+    for (i = 0; i < 64; i++) pt->w[i] = athres[i];
+    for (i = 0; i < npart; i++) pt->nsum[i] = part[i + 1] - part[i];
+    pt->npart_e = npart;
+    for (i = 0, t = 0; i < 64; i++) { pt->pstart[i] = t; t += pt->nsum[i]; }
+    pt->pstart[64] = t;
+}
+
+// Returns 0 when the configuration is outside what the MI355X path implements (the reference
+// would run MPEG-2, mono, dual-channel or intensity stereo there) or when the reference itself
+// rejects it (mp3enc.cpp:346-351,388); 9216 (bytes of float PCM per frame) otherwise.
+int hx_resolve(const HxControl *ec_arg, HxParams *p)
+{
+    static const int sr_all[8] = {22050, 24000, 16000, 1, 44100, 48000, 32000, 1};
+    static const int mnrGOLD[22] = {-5, 0, 0, 0, 0, 0, 0, 0, 0, 3, 5, 5, 5, 5, 3, 0, 0, 0, -1, -8, -10, 0};
+    HxControl ec = *ec_arg;
+    memset(p, 0, sizeof(*p));
+    if (ec.mode < 0) ec.mode = 1;
+    if (ec.mode > 3) ec.mode = 3;
+    if (ec.bitrate < 0) { ec.bitrate = 64; if (ec.samprate < 32000) ec.bitrate = 32; }
+    if (ec.mode == 2) ec.vbr_flag = 0;
+    ec.vbr_mnr = MN(MX(ec.vbr_mnr, 0), 150);
+    if (ec.mode != 1) ec.nsbstereo = 0;
+    if (ec.vbr_flag) ec.nsbstereo = 0;
+    if (ec.mode == 2) ec.hf_flag = 0;
+    if (ec.vbr_flag == 0) { if (ec.bitrate < 96) ec.hf_flag = 0; }
+    else { if (ec.vbr_mnr < 80) ec.hf_flag = 0; }
+    if (ec.samprate < 44100) ec.hf_flag = 0;
+    if (ec.filter_select < 0) ec.filter_select = 0;
+    if ((ec.vbr_flag == 0) && (ec.samprate > 24000) && (ec.bitrate < 48)) return 0;
+    ec.cr_bit &= 1;
+    ec.original &= 1;
+    if (ec.samprate > 32000) { if (ec.bitrate < 24) ec.bitrate = 24; }
+    else if (ec.samprate > 24000) { if (ec.bitrate < 16) ec.bitrate = 16; }
+    else if (ec.samprate > 16000) { if (ec.bitrate < 12) ec.bitrate = 12; }
+    else { if (ec.bitrate < 8) ec.bitrate = 8; }
+    p->short_block_threshold = ec.short_block_threshold;
+    if (ec.layer != 3) return 0;
+
+    int k = 0, dmin = 99999;
+    for (int i = 0; i < 8; i++) { int d = abs(ec.samprate - sr_all[i]); if (d < dmin) { dmin = d; k = i; } }
+    if ((k >> 2) != 1) return 0;                    // MPEG-2 LSF rates: not on this path
+    p->sr_index = k & 3;
+    if (ec.mode != 0 && ec.mode != 1) return 0;     // dual channel / mono: not on this path
+    p->h_mode = ec.mode;
+    int mode_ext = (p->h_mode == 1) ? ec.nsbstereo / 4 - 1 : 0;
+    mode_ext = MN(MX(mode_ext, 0), 3);
+    int bitrate = MX(ec.bitrate, 8) * 2;
+    if (bitrate > 320) bitrate = 320;
+    int br_index = 0;
+    for (int i = 1; br_mpeg1_l3[i] >= 0; i++) if (br_mpeg1_l3[i] == bitrate) br_index = i;
+    p->totbitrate = bitrate;
+    HxMpegHead *h = &p->head_info;
+    h->sync = 1; h->id = 1; h->option = 1; h->prot = 1; h->br_index = br_index; h->sr_index = p->sr_index;
+    h->mode = p->h_mode; h->mode_ext = mode_ext; h->cr = ec.cr_bit; h->original = ec.original;
+    p->head[0] = 0xFF;
+    p->head[1] = 0xFB;
+    p->head[2] = (unsigned char) ((br_index << 4) | (p->sr_index << 2));
+    p->head[3] = (unsigned char) ((p->h_mode << 6) | (mode_ext << 4) | (ec.cr_bit << 3) | (ec.original << 2));
+
+    p->nband = sfb_long[p->sr_index][21];
+    p->nsb = (p->nband + 17) / 18;
+    int nsbstereo = 12 * p->totbitrate / 32 - 20;
+    nsbstereo = MX(MN(nsbstereo, 32), 3);
+    if (p->totbitrate >= 96) nsbstereo = 32;
+    if (ec.vbr_flag) nsbstereo = 32;
+    if (ec.nsbstereo > 0) nsbstereo = MN(MX(ec.nsbstereo, 3), 32);
+    if (nsbstereo > p->nsb) nsbstereo = p->nsb;
+    p->samprate = sr_all[4 + p->sr_index];
+    p->divisor = p->samprate;
+    p->framebytes = 144000 * p->totbitrate / p->divisor;
+    p->remainder = (144000 * p->totbitrate) % p->divisor;
+    p->side_bytes = 32;
+    p->main_framebytes = p->framebytes - 4 - p->side_bytes;
+    p->sf_bit_max = 3 * (6 * 4 + 6 * 3);
+    p->AveTargetBits = ((8 * p->main_framebytes / 2) >> 1) - p->sf_bit_max;
+
+    int nsb_user_flag = 0, u1 = 32, u2 = 32, freq_limit;
+    if (ec.nsb_limit > 0) {
+        u1 = MN(ec.nsb_limit, 32);
+        u1 = MX(ec.nsb_limit, (64 * 1000 + p->samprate / 2) / p->samprate);
+        nsb_user_flag = 1;
+    }
+    if (ec.freq_limit < 24000) {
+        u2 = (64 * MX(ec.freq_limit, 1000) + p->samprate / 2) / p->samprate;
+        nsb_user_flag = 1;
+    }
+    int nsb_limit_user = MN(u1, u2);
+    if (ec.vbr_flag) {
+        freq_limit = 12000 + 80 * ec.vbr_mnr;
+        if (ec.vbr_mnr <= 5) freq_limit = 12000;
+        freq_limit = MN(freq_limit, ((int) ((0.96f * 0.5f) * p->samprate)));
+    } else {
+        static const float factor[4] = {1.1f, 1.333f, 1.0f, 1.0f};
+        float chan_bitrate = (float) p->totbitrate;
+        chan_bitrate = (float) (0.5 * chan_bitrate);
+        chan_bitrate = factor[p->h_mode] * chan_bitrate;
+        freq_limit = (int) (187.97 * chan_bitrate);
+    }
+    p->nsb_limit = nsb_user_flag ? nsb_limit_user : (64 * MX(freq_limit, 1000) + p->samprate / 2) / p->samprate;
+    p->nsb_limit = MN(p->nsb, p->nsb_limit);
+    p->nsb_ms0 = p->nsb_ms1 = p->nsb_limit;
+    if (p->nsb_limit < p->nsb) ec.hf_flag = 0;
+    if (ec.hf_flag) { p->nsb_ms0 = 29; if (nsb_user_flag) p->nsb_ms0 = MN(nsb_limit_user, 29); }
+    if (ec.hf_flag & 2) { p->nsb_ms1 = 29; if (nsb_user_flag) p->nsb_ms1 = MN(nsb_limit_user, 29); }
+    p->band_limit = MN(18 * p->nsb_limit, p->nband);
+    int nsbstereo_limit = MN(nsbstereo, p->nsb_limit);
+    p->band_limit_stereo = (p->h_mode == 1) ? 18 * nsbstereo_limit : p->band_limit;
+    if (p->band_limit_stereo > p->band_limit) p->band_limit_stereo = p->band_limit;
+
+    p->filter_alpha = (float) (0.001 * 44100.0 / p->samprate);
+    p->filter_dc = ec.filter_select > 1 ? 1 : ec.filter_select;
+
+    for (int i = 0; i < 22; i++) p->nBand_l_iso[i] = p->nBand_l[i] = sfb_long[p->sr_index][i + 1] - sfb_long[p->sr_index][i];
+    for (int i = 0; i < 13; i++) p->nBand_s[i] = sfb_short[p->sr_index][i + 1] - sfb_short[p->sr_index][i];
+    transform_tables(p);
+    psy_long_tables(p);
+
+    int is_flag = 0;
+    p->ms_flag = 0;
+    if (p->h_mode == 1) { if (nsbstereo_limit < p->nsb_limit) is_flag = 1; p->ms_flag = 1; }
+    if (is_flag) return 0;                          // intensity stereo (legacy allocator): not on this path
+    p->vbr_flag = ec.vbr_flag;
+    if (ec.vbr_flag) {                              // gen_vbr_table (mp3enc.cpp:964-1041)
+        for (int i = 1; i < 15; i++) {
+            int mb = 144000 * br_mpeg1_l3[i] / p->samprate;
+            p->vbr_framebytes[i] = mb;
+            p->vbr_main_framebytes[i] = mb - 4 - 32;
+        }
+        p->vbr_framebytes[15] = p->vbr_main_framebytes[15] = 9999999;
+        p->vbr_pool_target = 256;
+        int i;
+        for (i = 14; i >= 2; i--) {
+            if (2 * ec.vbr_br_limit >= br_mpeg1_l3[i]) break;
+            p->vbr_pool_target = (p->vbr_pool_target + 511) >> 1;
+        }
+        p->ivbr_max = i;
+        p->ivbr_min = 1;
+        p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / 4) - p->sf_bit_max;
+        p->initialMNR = MN(MX(10 * ec.vbr_mnr, 210), 1500);
+    } else {
+        p->initialMNR = MN(MX(125 * (p->totbitrate / 2 - 32) / 8, 0), 1000);
+    }
+    ec.vbr_delta_mnr = MX(MN(ec.vbr_delta_mnr, 50), -40);
+    for (int i = 0; i < 21; i++) ec.mnr_adjust[i] = MX(MN(ec.mnr_adjust[i], 200), -200);
+    p->hf_flag = ec.hf_flag;
+    p->test1 = ec.test1 < 0 ? 6 : ec.test1;
+
+    p->nsf3[0] = p->nsf2[0] = p->nsf[0] = sfbl_limit(p->sr_index, p->band_limit);
+    p->nsf3[1] = p->nsf2[1] = p->nsf[1] = sfbl_limit(p->sr_index, p->band_limit_stereo);
+    if (p->hf_flag) { p->nsf2[0] = 22; p->nBand_l[21] = 100; }
+    if (p->hf_flag & 2) { p->nsf3[0] = 22; p->nsf3[1] = 22; }
+    k = 0;
+    for (int i = 0; i < 22; i++) { p->startBand_l[i] = k; k += p->nBand_l[i]; }
+    p->startBand_l[22] = k;
+    p->startBand_l[23] = 576;
+    k = 0;
+    for (int i = 0; i < 13; i++) { p->startBand_s[i] = k; k += p->nBand_s[i]; }
+    p->startBand_s[13] = k;
+    for (int j = 0; j < 2; j++) p->nbmax3[j] = p->nbmax2[j] = p->nbmax[j] = p->startBand_l[p->nsf[j]];
+    if (p->hf_flag) p->nbmax2[0] = p->startBand_l[p->nsf2[0]];
+    if (p->hf_flag & 2) { p->nbmax3[0] = p->startBand_l[p->nsf3[0]]; p->nbmax3[1] = p->startBand_l[p->nsf3[1]]; }
+    for (int i = 0; i < 576; i++) {
+        int b = 21;
+        for (int j = 0; j < 22; j++) if (i < p->startBand_l[j + 1]) { b = j; break; }
+        p->band_of_line[i] = (unsigned char) b;
+    }
+    for (int i = 0; i < 128; i++) {
+        p->look_gain[i] = (float) (pow(2.0, 0.25 * (i - 8)));
+        p->look_34igain[i] = (float) (1.0 / pow((double) p->look_gain[i], (double) (3.0 / 4.0)));
+    }
+    for (int i = 0; i < 256; i++) p->look_ix43[i] = (float) (i * pow((double) i, (double) (1.0 / 3.0)));
+    for (int i = 0; i < 21; i++) p->look_log_cbwmb[i] = (int) (100.0f * (float) (10.0 * log10((double) (float) p->nBand_l[i])));
+    if (!ec.quick) {                                 // taper for the legacy FFT model (bitallo3.cpp:410-432)
+        for (int i = 11; i < 22; i++) p->taperNT[i] = 100 + MN(150, 20 * (i - 11));
+        if (p->vbr_flag) for (int i = 11; i < 22; i++) p->taperNT[i] = MN(p->taperNT[i], p->initialMNR);
+        for (int i = 0; i < 21; i++) p->taperNT[i] -= 10 * mnrGOLD[i];
+    }
+    p->initialMNR += 10 * ec.vbr_delta_mnr;
+    for (int i = 0; i < 22; i++) if (p->nBand_l[i] != 0) p->rnBand_l[i] = (1.0f / p->nBand_l[i]);
+
+    p->ec = ec;
+    p->ec.mode = p->h_mode;
+    p->ec.bitrate = p->totbitrate / 2;
+    p->ec.samprate = p->samprate;
+    p->ec.nsbstereo = 32;
+    p->ec.freq_limit = ec.hf_flag ? ec.freq_limit : p->nsb_limit * (p->samprate / 64);
+    p->ec.nsb_limit = p->nsb_limit;
+    p->ec.layer = 3;
+    return 2 * 4 * 1152;
+}
+
+// Initial per-stream state (mp3enc.cpp:278-287,614-621,788-837; bitallo3.cpp:300-316)
+void hx_stream_reset(const HxParams *p, int cls, HxStream *s)
+{
+    memset(s, 0, sizeof(*s));
+    s->cls = cls;
+    for (int i = 0; i < 32; i++) s->attack_hist[0][i] = s->attack_hist[1][i] = 9000;
+    for (int c = 0; c < 2; c++) for (int i = 0; i < 64; i++) s->thr_prev[c][i] = 1.0e20f;
+    s->MNR = p->initialMNR;
+    s->PoolFraction = p->vbr_flag ? 614 : 0;
+    s->padcount = p->divisor;
+}

@@ -1,0 +1,121 @@
+// hx_types.h - POD layouts shared by the host runtime and the HIP kernels of the
+// MI355X batched MP3 encoder.  Domain names follow the reference (granule, sfb, part2_3...).
+#pragma once
+#include <stdint.h>
+
+// Same field order as the reference's E_CONTROL (pub/encapp.h:42-72): passed verbatim
+// through the C-ABI.
+struct HxControl {
+    int mode, bitrate, samprate, nsbstereo, filter_select, freq_limit, nsb_limit;
+    int layer, cr_bit, original, hf_flag, vbr_flag, vbr_mnr, vbr_br_limit, vbr_delta_mnr;
+    int chan_add_f0, chan_add_f1, sparse_scale;
+    int mnr_adjust[21];
+    int cpu_select, quick, test1, test2, test3, short_block_threshold;
+};
+
+// MPEG_HEAD (pub/encapp.h:141-157)
+struct HxMpegHead {
+    int sync, id, option, prot, br_index, sr_index, pad, private_bit, mode, mode_ext, cr, original, emphasis;
+};
+
+// Psychoacoustic tables of one block class (long = 2 partitions per sfb)
+struct HxPsyTab {
+    int npart;          // spreading rows
+    int npart_e;        // energy partitions
+    int nsum[64];       // lines per partition
+    int pstart[65];     // first line of partition
+    int cnt[64], off[64], row[64];  // spreading row: length, first source partition, offset into w
+    float w[2200];      // [0..63] absolute threshold x width, rows from 128
+};
+
+// Everything resolved at init for one configuration class (sample rate / bitrate / flags).
+// Lives in device global memory; kernels index it through HxStream::cls.
+struct HxParams {
+    HxControl ec;           // echoed control (L3_audio_encode_info_ec)
+    HxMpegHead head_info;
+    unsigned char head[4];
+    int totbitrate, samprate, sr_index, h_mode;
+    int nband, nsb, nsb_limit, nsb_ms0, nsb_ms1, band_limit, band_limit_stereo;
+    int framebytes, remainder, divisor, main_framebytes, side_bytes, sf_bit_max, AveTargetBits;
+    int ms_flag, hf_flag, vbr_flag, short_block_threshold, filter_dc;
+    float filter_alpha;
+    int ivbr_min, ivbr_max, vbr_main_framebytes[16], vbr_framebytes[16], vbr_pool_target;
+    int initialMNR, test1, taperNT[22];
+    int nBand_l_iso[22];
+    int nBand_l[22], startBand_l[24], nBand_s[13], startBand_s[14];
+    int nsf[2], nsf2[2], nsf3[2], nbmax[2], nbmax2[2], nbmax3[2];
+    int look_log_cbwmb[22];
+    float rnBand_l[22];
+    unsigned char band_of_line[576];    // sfb index of each MDCT line (allocator's band table)
+    float dct_coef[32];
+    float win[4][36], csa[2][8];
+    float m18_w[18], m18_w2[9], m18_c[9][4];
+    float m6_v[6], m6_v2[3], m6_c87;
+    HxPsyTab psyL;
+    float look_gain[128], look_34igain[128], look_ix43[256];
+};
+
+// Class-independent tables.
+struct HxGlobalTabs {
+    float anwin[512];
+    int mblog[256];
+    float mbexp_lo[256], mbexp_hi[256];
+    float pow34_exp[256], pow34_a[16], pow34_b[16];
+    float quant_off[32];
+    int logsub[84];
+    unsigned short huff_code[1408];     // 1378 used (ISO Table B.7 at true dimensions)
+    unsigned char huff_len[1408];
+    unsigned short huff_off[32];
+    unsigned char huff_dim[32], huff_lin[32];
+    unsigned char quada_code[16], quada_len[16];
+};
+
+// Side information of one granule/channel (pub/l3e.h:72-96)
+struct HxGr {
+    int part2_3_length, big_values, global_gain, scalefac_compress;
+    int window_switching_flag, block_type, mixed_block_flag;
+    int table_select[3], subblock_gain[3];
+    int region0_count, region1_count, preflag, scalefac_scale, count1table_select;
+    int aux_nquads, aux_bits, aux_not_null, aux_nreg[3];
+};
+
+#define HX_MAINBUF (16384 + 512 + 1440 + 256)
+
+// Persistent per-stream state (device global memory).  It is the checkpoint unit: copying
+// this struct plus the subband carry is a complete snapshot of a stream.
+struct HxStream {
+    int cls;                    // index into the HxParams array
+    int frames_in;              // frames submitted so far
+    // front end
+    float dc[2];
+    float pcm_hist[2][480];     // last 480 filtered samples per channel (oldest first)
+    int attack_hist[2][32];     // energy history in mB (detect.c)
+    int bt_prev;                // block type of the previous granule
+    int short_flag_next_prev;   // short_flag_next of the previous granule
+    float thr_prev[2][64];      // previous granule's unclamped thresholds x 2 (ecsave)
+    // allocator
+    int MNR, PoolFraction, call_count, ms_memory, NTadjust[2][22];
+    int sf_save[2][21];
+    int gr_subblock_gain[2][2][3];
+    // reservoir / frame assembly (mp3enc.cpp:2230-2333)
+    int padcount;
+    unsigned main_tot, main_sent, mf_tot;
+    int main_bytes, main_p0, main_p1;
+    unsigned side_p0, side_p1;
+    unsigned frame_main_pos[32];
+    int frame_mf_bytes[32];
+    unsigned char mode_ext_buf[32], br_index_buf[32], side_buf[32][32];
+    unsigned tot_frames_out, tot_bytes_out;
+    int ave_tot_bytes_out;
+    unsigned char main_buf[HX_MAINBUF];
+};
+
+// Optional per-frame debug taps written by the allocator kernel (tests only).
+struct HxFrameDebug {
+    int ms, ms_metric[2], byte_pool, MNR_after;
+    int mask_mb[2][2][22];      // [gr][ch] mbLog of the per-sfb mask
+    HxGr gr[2][2];
+    int sf[2][2][22];
+    int scfsi[2];
+    int main_bytes;             // bytes of main data produced by this frame (before padding)
+};

@@ -1,0 +1,108 @@
+/*
+ * hmp3_amd.h - C ABI of the MI355X-native batched MP3 (MPEG-1 Layer III) encoder.
+ *
+ * Drop-in boundary for the Helix encoder's frame-encode path: every hx_enc_* entry point
+ * replaces one public method of the reference's `class CMp3Enc`
+ * (/root/reference/hmp3/src/pub/mp3enc.h:74-139), with the same argument meaning, the same
+ * return values and the same error behaviour (init returns 0 on failure; encode cannot fail).
+ * E_CONTROL / MPEG_HEAD / IN_OUT / INT_PAIR are the reference's plain structs
+ * (pub/encapp.h:42-72,141-165; pub/mp3enc.h:66-71) and cross this ABI unchanged.
+ *
+ * The hx_batch_* entry points have no reference equivalent: they encode N independent streams
+ * x F frames per call on one GPU, which is where the throughput comes from.  All buffers are
+ * plain pointers; "device" variants take HIP device pointers and a hipStream_t (as void*).
+ *
+ * Everything runs on the GPU: there is no CPU fallback.  If no MI355X-class device is usable
+ * the create calls return NULL / init returns 0 and hx_last_error() says why.
+ */
+#ifndef HMP3_AMD_H
+#define HMP3_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pub/encapp.h:42-72 */
+typedef struct {
+    int mode, bitrate, samprate, nsbstereo, filter_select, freq_limit, nsb_limit;
+    int layer, cr_bit, original, hf_flag, vbr_flag, vbr_mnr, vbr_br_limit, vbr_delta_mnr;
+    int chan_add_f0, chan_add_f1, sparse_scale;
+    int mnr_adjust[21];
+    int cpu_select, quick, test1, test2, test3, short_block_threshold;
+} HX_E_CONTROL;
+
+/* pub/encapp.h:141-157 */
+typedef struct {
+    int sync, id, option, prot, br_index, sr_index, pad, private_bit, mode, mode_ext, cr, original, emphasis;
+} HX_MPEG_HEAD;
+
+typedef struct { int in_bytes, out_bytes; } HX_IN_OUT;      /* pub/encapp.h:160-165 */
+typedef struct { int a, b; } HX_INT_PAIR;                   /* pub/mp3enc.h:66-71 */
+
+typedef struct hx_enc hx_enc;       /* one stream, CMp3Enc-compatible */
+typedef struct hx_batch hx_batch;   /* N streams on one GPU */
+
+const char *hx_last_error(void);
+int hx_device_count(void);
+void hx_default_control(HX_E_CONTROL *ec);                  /* CLI defaults, test/tomp3.cpp:357-384 */
+
+/* ---- CMp3Enc replacement (one stream, host buffers) ---- */
+hx_enc *hx_enc_create(int device);                          /* CMp3Enc::CMp3Enc,  mp3enc.cpp:115 */
+void hx_enc_destroy(hx_enc *e);                             /* CMp3Enc::~CMp3Enc, mp3enc.cpp:201 */
+/* CMp3Enc::L3_audio_encode_init (mp3enc.cpp:220): returns bytes of float PCM per call (9216) or 0 */
+int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec);
+/* CMp3Enc::L3_audio_encode (mp3enc.cpp:2031): 1152 x 2 floats at int16 scale, oldest first */
+HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out);
+/* CMp3Enc::MP3_audio_encode_init (mp3enc.cpp:2655): 16-bit or float source at a native MPEG-1
+   rate, no rate conversion; returns min input bytes per call or 0 */
+int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, int source_bits, int source_is_float,
+                                 int mpeg_select, int mono_convert);
+/* CMp3Enc::MP3_audio_encode (mp3enc.cpp:2812) */
+HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out);
+int hx_enc_get_bitrate(hx_enc *e);                          /* mp3enc.cpp:3444 */
+float hx_enc_get_bitrate_float(hx_enc *e);                  /* mp3enc.cpp:3451 */
+float hx_enc_get_bitrate2_float(hx_enc *e);                 /* mp3enc.cpp:3468 */
+unsigned hx_enc_get_frames(hx_enc *e);                      /* mp3enc.cpp:3484 */
+HX_INT_PAIR hx_enc_get_frames_bytes(hx_enc *e);             /* mp3enc.cpp:3512 */
+void hx_enc_info_ec(hx_enc *e, HX_E_CONTROL *ec);           /* mp3enc.cpp:3491 */
+void hx_enc_info_head(hx_enc *e, HX_MPEG_HEAD *head);       /* mp3enc.cpp:3498 */
+void hx_enc_info_string(hx_enc *e, char *s);                /* mp3enc.cpp:3505, <= 80 chars */
+
+/* ---- batched encode (N independent streams) ---- */
+/* ec: nstreams controls, or one shared control when shared_control != 0.
+   max_frames: largest nframes any later call will pass.  Returns NULL on failure. */
+hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTROL *ec, int shared_control, int max_frames);
+void hx_batch_destroy(hx_batch *b);
+int hx_batch_nstreams(const hx_batch *b);
+/* worst-case bytes one stream can emit in a call of nframes frames */
+long long hx_batch_out_stride(const hx_batch *b, int nframes);
+/* PCM: int16 interleaved L/R, [nstreams][nframes*1152][2]; out: [nstreams][out_stride] bytes;
+   out_bytes: [nstreams] bytes produced (whole frames; the frames emitted are exactly those the
+   reference emits over the same nframes calls).  stream: hipStream_t or NULL.
+   Asynchronous on `stream`.  Returns 0, or a negative error. */
+int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
+                               long long out_stride, int *d_out_bytes, void *stream);
+/* same with host buffers (staged through the device, synchronous) */
+int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out,
+                             long long out_stride, int *out_bytes);
+/* status bits accumulated by the kernels: 1 = a short block was selected (not on the GPU path
+   yet), 2 = main data overflow (the reference would assert).  Synchronises. */
+int hx_batch_status(hx_batch *b);
+/* total frames / bytes emitted so far by stream i (synchronises) */
+HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int stream_index);
+/* mean device time of the dominant (allocator) kernel over the calls since the last query, in
+   milliseconds, measured with HIP events on the launch stream; also returns the call count */
+float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls);
+
+/* ---- test taps (tests only; synchronise) ---- */
+/* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg"; copies at most cap bytes, returns bytes */
+long long hx_batch_debug_read(hx_batch *b, const char *name, void *dst, long long cap);
+void hx_batch_debug_enable(hx_batch *b, int on);
+/* host-side table generation for the CPU tests (no GPU): see hx_cabi.hip */
+long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *name, void *dst, long long cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

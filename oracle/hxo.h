@@ -128,10 +128,29 @@ typedef struct {
     int last_ms, last_attack[2][2], last_ms_metric[2];
 } hxo_state;
 
+/* per-frame taps for stage-wise tests (filled when hxo_set_debug() has been called) */
+typedef struct {
+    float sample_new[2][2][576];    /* [gr][ch] subband granule produced by this call */
+    float xr_pre[2][2][576];        /* [gr][ch] spectrum before the allocator mutates it */
+    float etab[2][2][64], thr[2][2][64];    /* psy: partition energy+ATH, unclamped threshold */
+    float mask[2][2][22];
+    int block_type[2], attack[2][2];
+    int ms, ms_metric[2], byte_pool, MNR_after;
+    hxo_gr gr[2][2];
+    int sf[2][2][22];
+    int ix[2][2][576];
+    unsigned char signx[2][2][576];
+    int scfsi[2];
+    int main_bytes;
+} hxo_frame_debug;
+
 typedef struct hxo_encoder {
     hxo_params p;
     hxo_state s;
+    hxo_frame_debug *dbg;
 } hxo_encoder;
+void hxo_set_debug(hxo_encoder *e, hxo_frame_debug *d);
+int hxo_sizeof_frame_debug(void);
 
 /* --- API --- */
 hxo_encoder *hxo_new(void);

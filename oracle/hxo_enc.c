@@ -11,6 +11,9 @@
 hxo_encoder *hxo_new(void) { return (hxo_encoder *) calloc(1, sizeof(hxo_encoder)); }
 void hxo_free(hxo_encoder *e) { free(e); }
 int hxo_sizeof_encoder(void) { return (int) sizeof(hxo_encoder); }
+int hxo_sizeof_frame_debug(void) { return (int) sizeof(hxo_frame_debug); }
+void hxo_set_debug(hxo_encoder *e, hxo_frame_debug *d) { e->dbg = d; }
+extern float *hxo_tap_etab, *hxo_tap_thr;
 unsigned hxo_frames_out(const hxo_encoder *e) { return e->s.tot_frames_out; }
 unsigned hxo_bytes_out(const hxo_encoder *e) { return e->s.tot_bytes_out; }
 
@@ -375,15 +378,36 @@ static int encode_joint(hxo_encoder *e, hxo_bitw *w)
         if ((m1 + m2) >= 0) ms = 1;
     }
 
+    if (e->dbg) {
+        e->dbg->ms = ms; e->dbg->ms_metric[0] = s->last_ms_metric[0]; e->dbg->ms_metric[1] = s->last_ms_metric[1];
+        e->dbg->byte_pool = s->byte_pool;
+        memcpy(e->dbg->xr_pre, s->xr, sizeof(s->xr));
+        for (igr = 0; igr < 2; igr++) {
+            e->dbg->block_type[igr] = s->block_type[igr];
+            for (ch = 0; ch < 2; ch++) {
+                e->dbg->attack[igr][ch] = s->last_attack[igr][ch];
+                /* subband granule computed in this call for (igr, ch): slot written by transform_granule */
+                memcpy(e->dbg->sample_new[igr][ch], s->sample[ch][(s->igrx + igr) & 3], 576 * sizeof(float));
+            }
+        }
+    }
     for (igr = 0; igr < 2; igr++) {
         int bt = s->block_type[igr];
         for (ch = 0; ch < 2; ch++) {
+            if (e->dbg) { hxo_tap_etab = e->dbg->etab[igr][ch]; hxo_tap_thr = e->dbg->thr[igr][ch]; }
             if (bt != 2) hxo_psy_long(p, s->xr[igr][ch], s->ecsave[ch], s->sig_mask[ch], bt);
             else hxo_psy_short(p, s->xr[igr][ch], s->ecsave[ch], s->sig_mask[ch], s->block_type_prev[igr]);
+            hxo_tap_etab = hxo_tap_thr = 0;
+            if (e->dbg) { int i; for (i = 0; i < 22; i++) e->dbg->mask[igr][ch][i] = s->sig_mask[ch][i].mask; }
         }
         s->gr[igr][0].block_type = s->gr[igr][1].block_type = bt;
         hxo_bitallo_long(e, s->xr[igr], s->sig_mask, ba_min, TargetBits, ba_max, bit_pool,
                          s->sf[igr], s->gr[igr], ms);
+        if (e->dbg) {
+            memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
+            memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+            for (ch = 0; ch < 2; ch++) { int i; for (i = 0; i < 22; i++) e->dbg->sf[igr][ch][i] = s->sf[igr][ch].l[i]; }
+        }
         for (ch = 0; ch < 2; ch++) {
             hxo_gr *g = &s->gr[igr][ch];
             bits = 0;
@@ -437,6 +461,12 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
     s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms);
     bytes = hxo_bw_flush(&w);
     assert(bytes <= s->byte_max);
+    if (e->dbg) {
+        memcpy(e->dbg->gr, s->gr, sizeof(s->gr));
+        e->dbg->scfsi[0] = s->scfsi[0]; e->dbg->scfsi[1] = s->scfsi[1];
+        e->dbg->MNR_after = s->MNR;
+        e->dbg->main_bytes = bytes;
+    }
     if (p->vbr_flag) {
         int bytes2 = bytes - s->byte_pool, bytes3 = bytes2 + p->vbr_pool_target;
         for (ibr = p->ivbr_min; ibr <= p->ivbr_max; ibr++) if (bytes2 <= p->vbr_main_framebytes[ibr]) break;
@@ -495,4 +525,31 @@ int hxo_encode_frame_s16(hxo_encoder *e, const int16_t *pcm, unsigned char *out)
     int i;
     for (i = 0; i < 2304; i++) f[i] = (float) pcm[i];
     return hxo_encode_frame(e, f, out);
+}
+
+/* test accessor: copy a named init-time table of an initialised encoder (returns bytes, -1 = unknown) */
+long long hxo_debug_table(const hxo_encoder *e, const char *name, void *dst, long long cap)
+{
+    const hxo_params *p = &e->p;
+    const void *src = 0;
+    long long n = 0;
+    static int v[16];
+#define TAB(nm, obj) if (!strcmp(name, nm)) { src = &(obj); n = sizeof(obj); }
+    TAB("psy_w", p->psyL.w) TAB("psy_cnt", p->psyL.cnt) TAB("psy_off", p->psyL.off) TAB("psy_nsum", p->psyL.nsum)
+    TAB("psy_npart", p->psyL.npart) TAB("dct_coef", p->dct_coef) TAB("win", p->win) TAB("csa", p->csa)
+    TAB("m18_w", p->m18_w) TAB("m18_w2", p->m18_w2) TAB("m18_c", p->m18_c)
+    TAB("look_gain", p->look_gain) TAB("look_34igain", p->look_34igain) TAB("look_ix43", p->look_ix43)
+    TAB("look_log_cbwmb", p->look_log_cbwmb) TAB("nBand_l", p->nBand_l) TAB("startBand_l", p->startBand_l)
+    TAB("nsf", p->nsf) TAB("taperNT", p->taperNT) TAB("head", p->head) TAB("ec", p->ec)
+#undef TAB
+    if (!strcmp(name, "scalars")) {
+        v[0] = p->nsb_limit; v[1] = p->nsb_limitMS[0]; v[2] = p->band_limit; v[3] = p->main_framebytes; v[4] = p->AveTargetBits;
+        v[5] = p->initialMNR; v[6] = p->ms_flag; v[7] = p->hf_flag; v[8] = p->vbr_flag; v[9] = p->framebytes;
+        v[10] = p->remainder; v[11] = p->ivbr_max; v[12] = p->vbr_pool_target; v[13] = p->samprate; v[14] = p->totbitrate; v[15] = p->nsb_limitMS[1];
+        src = v; n = sizeof(v);
+    }
+    if (!src) return -1;
+    if (n > cap) n = cap;
+    memcpy(dst, src, (size_t) n);
+    return n;
 }

@@ -264,12 +264,15 @@ int hxo_attack_detect(const float *sample, int eng[32], int short_flag_prev)
     return m;
 }
 
+/* test taps: when set, hxo_psy_long also stores etab and the unclamped thresholds */
+float *hxo_tap_etab, *hxo_tap_thr;
+
 /* emap.c:96-121 + spdsmr.c:188-320 */
 void hxo_psy_long(const hxo_params *p, const float *xr, float *esave, hxo_sigmask *sm, int block_type)
 {
     const hxo_psytab *pt = &p->psyL;
     const float *w = pt->w;
-    float e[64], xtab[64], stab[64], etab[64];
+    float e[64], xtab[64], stab[64] = {0}, etab[64];
     int mbetab[64];
     int i, j, k, n, q, m, npart, npart2;
     int snr, snr0, totsnr, nsnr, d, d0, dm0, dm, snrvar, dv, itmp;
@@ -322,6 +325,10 @@ void hxo_psy_long(const hxo_params *p, const float *xr, float *esave, hxo_sigmas
         float a, s1, s2, t, x, emax, s;
         dm = HXO_MAX(dm0 * HXO_MAX(m - 13, 0), 0);
         a = hxo_mbexp(d + dm);
+        if (hxo_tap_etab) {
+            hxo_tap_etab[i] = etab[i]; hxo_tap_etab[i + 1] = etab[i + 1];
+            hxo_tap_thr[i] = a * stab[i]; hxo_tap_thr[i + 1] = a * stab[i + 1];
+        }
         s1 = a * stab[i];
         t = esave[i];
         esave[i] = (float) (2.0 * s1);

@@ -160,3 +160,33 @@ def encode_stream(enc, pcm_i16, flush_frames=2):
     for _ in range(flush_frames):
         out.append(enc.encode_s16(z))
     return b"".join(out)
+
+
+GR_FIELDS = ["part2_3_length", "big_values", "global_gain", "scalefac_compress", "window_switching_flag",
+             "block_type", "mixed_block_flag", "table_select0", "table_select1", "table_select2",
+             "subblock_gain0", "subblock_gain1", "subblock_gain2", "region0_count", "region1_count",
+             "preflag", "scalefac_scale", "count1table_select", "aux_nquads", "aux_bits", "aux_not_null",
+             "aux_nreg0", "aux_nreg1", "aux_nreg2"]
+
+
+class FrameDebug(C.Structure):
+    """hxo_frame_debug (oracle/hxo.h)"""
+    _fields_ = [
+        ("sample_new", C.c_float * (2 * 2 * 576)), ("xr_pre", C.c_float * (2 * 2 * 576)),
+        ("etab", C.c_float * (2 * 2 * 64)), ("thr", C.c_float * (2 * 2 * 64)), ("mask", C.c_float * (2 * 2 * 22)),
+        ("block_type", C.c_int * 2), ("attack", C.c_int * 4),
+        ("ms", C.c_int), ("ms_metric", C.c_int * 2), ("byte_pool", C.c_int), ("MNR_after", C.c_int),
+        ("gr", C.c_int * (2 * 2 * 27)), ("sf", C.c_int * (2 * 2 * 22)), ("ix", C.c_int * (2 * 2 * 576)),
+        ("signx", C.c_ubyte * (2 * 2 * 576)), ("scfsi", C.c_int * 2), ("main_bytes", C.c_int)]
+
+
+def oracle_enable_debug(enc):
+    """attach a FrameDebug record to an OracleEncoder; returns it (refilled on every frame)"""
+    l = lib()
+    l.hxo_sizeof_frame_debug.restype = C.c_int
+    assert l.hxo_sizeof_frame_debug() == C.sizeof(FrameDebug), (l.hxo_sizeof_frame_debug(), C.sizeof(FrameDebug))
+    d = FrameDebug()
+    l.hxo_set_debug.argtypes = [C.c_void_p, C.c_void_p]
+    l.hxo_set_debug(enc.h, C.byref(d))
+    enc._dbg = d
+    return d

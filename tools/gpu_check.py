@@ -1,0 +1,146 @@
+"""Stage-by-stage comparison of the HIP pipeline against the oracle on a real GPU.
+Usage: python tools/gpu_check.py [nstreams] [nframes] [config]
+Prints the first stage / frame where the two differ (everything is expected to be bit-exact).
+"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+from oracle import oracle as O
+from hmp3_amd import api, synth
+
+CONFIGS = {
+    "cbr128": dict(bitrate=64, short_block_threshold=99999),
+    "cbr128lr": dict(bitrate=64, mode=0, short_block_threshold=99999),
+    "vbr50": dict(short_block_threshold=99999),
+    "cbr192": dict(bitrate=96, short_block_threshold=99999),
+    "vbr100hf": dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000, short_block_threshold=99999),
+    "cbr128_32k": dict(bitrate=64, samprate=32000, short_block_threshold=99999),
+}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "cbr128"
+    kw = CONFIGS[cfg]
+    sr = kw.get("samprate", 44100)
+    rhos = [0.7, 0.0, 1.0, 0.3]
+    pcm = np.stack([synth.stream_pcm(i, F, sr=sr, rho=rhos[i % 4]) for i in range(S)])
+    ec_o = O.default_control(**kw)
+    ec_g = api.default_control(**kw)
+    # oracle, with taps
+    odbg = []
+    obytes = []
+    osamp = np.zeros((S, 2, 2 * F, 576), dtype=np.float32)
+    for s in range(S):
+        enc = O.OracleEncoder(ec_o)
+        d = O.oracle_enable_debug(enc)
+        out = []
+        fr = []
+        for f in range(F):
+            out.append(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]))
+            rec = {k: np.array(getattr(d, k)) for k in ("xr_pre", "etab", "thr", "mask", "gr", "sf", "ix", "signx", "sample_new")}
+            rec.update(ms=d.ms, ms_metric=list(d.ms_metric), MNR_after=d.MNR_after, main_bytes=d.main_bytes,
+                       byte_pool=d.byte_pool, scfsi=list(d.scfsi))
+            fr.append(rec)
+            sn = rec["sample_new"].reshape(2, 2, 576)
+            for igr in range(2):
+                for ch in range(2):
+                    osamp[s, ch, 2 * f + igr] = sn[igr, ch]
+        obytes.append(b"".join(out))
+        odbg.append(fr)
+    # GPU
+    t0 = time.time()
+    b = api.Batch(ec_g, nstreams=S, max_frames=F)
+    b.debug_enable(True)
+    gbytes = b.encode_host(pcm)
+    print("gpu encode %.3fs status=%d" % (time.time() - t0, b.status()))
+    NG = 2 * F
+    SG = NG + 3
+    sb = b.debug_read("sb", np.float32, S * 2 * SG * 576).reshape(S, 2, SG, 576)
+    # k_carry has rolled the buffer: slots 0..2 now hold the last three granules
+    xr = b.debug_read("xr", np.float32, S * NG * 1152).reshape(S, NG, 2, 576)
+    etab = b.debug_read("etab", np.float32, S * NG * 128).reshape(S, NG, 2, 64)
+    thr = b.debug_read("thr", np.float32, S * NG * 128).reshape(S, NG, 2, 64)
+    msbase = b.debug_read("msbase", np.int32, S * NG).reshape(S, NG)
+    ok = True
+    # K1: subband samples (slot g+3 holds the granule computed at step g)
+    for s in range(S):
+        for ch in range(2):
+            a = bits(sb[s, ch, 3:3 + NG]); o = bits(osamp[s, ch])
+            if not np.array_equal(a, o):
+                g = int(np.argmax((a != o).any(axis=1)))
+                print("K1 polyphase mismatch stream %d ch %d granule %d  maxabs %g" % (s, ch, g, np.abs(sb[s, ch, 3 + g] - osamp[s, ch, g]).max()))
+                ok = False
+                break
+    print("K1 polyphase", "OK" if ok else "MISMATCH")
+    stages = [("K3 mdct xr", xr, "xr_pre", 576), ("K4 psy etab", etab, "etab", 42), ("K4 psy thr", thr, "thr", 42)]
+    for name, arr, key, n in stages:
+        good = True
+        for s in range(S):
+            for f in range(F):
+                o = odbg[s][f][key].reshape(2, 2, -1)
+                for igr in range(2):
+                    for ch in range(2):
+                        a = arr[s, 2 * f + igr, ch, :n]
+                        if not np.array_equal(bits(a), bits(o[igr, ch, :n])):
+                            if good:
+                                i = int(np.argmax(bits(a) != bits(o[igr, ch, :n])))
+                                print("%s mismatch stream %d frame %d gr %d ch %d idx %d gpu %r oracle %r" % (name, s, f, igr, ch, i, a[i], o[igr, ch, i]))
+                            good = False
+        print(name, "OK" if good else "MISMATCH")
+        ok &= good
+    # allocator taps
+    class GDbg(C.Structure):
+        _fields_ = [("ms", C.c_int), ("ms_metric", C.c_int * 2), ("byte_pool", C.c_int), ("MNR_after", C.c_int),
+                    ("mask_mb", C.c_int * 88), ("gr", C.c_int * (4 * 24)), ("sf", C.c_int * 88), ("scfsi", C.c_int * 2),
+                    ("main_bytes", C.c_int)]
+    raw = b.debug_read("dbg", np.uint8, S * F * C.sizeof(GDbg))
+    good = True
+    for s in range(S):
+        for f in range(F):
+            g = GDbg.from_buffer_copy(raw[(s * F + f) * C.sizeof(GDbg):(s * F + f + 1) * C.sizeof(GDbg)].tobytes())
+            o = odbg[s][f]
+            ogr = o["gr"].reshape(2, 2, 27)[:, :, :24].reshape(-1)
+            diffs = []
+            if g.ms != o["ms"] or list(g.ms_metric) != o["ms_metric"]:
+                diffs.append("ms %d %s vs %d %s" % (g.ms, list(g.ms_metric), o["ms"], o["ms_metric"]))
+            if g.byte_pool != o["byte_pool"]:
+                diffs.append("byte_pool %d vs %d" % (g.byte_pool, o["byte_pool"]))
+            if g.MNR_after != o["MNR_after"]:
+                diffs.append("MNR %d vs %d" % (g.MNR_after, o["MNR_after"]))
+            ggr = np.array(g.gr)
+            if not np.array_equal(ggr, ogr):
+                idx = np.nonzero(ggr != ogr)[0]
+                diffs.append("gr fields " + ", ".join("%s[gr%d ch%d] %d vs %d" % (O.GR_FIELDS[i % 24], i // 48, (i // 24) % 2, ggr[i], ogr[i]) for i in idx[:8]))
+            if not np.array_equal(np.array(g.sf), o["sf"].reshape(-1)):
+                diffs.append("sf gpu %s\n      oracle %s" % (list(np.array(g.sf)), list(o["sf"].reshape(-1))))
+            if list(g.scfsi) != o["scfsi"]:
+                diffs.append("scfsi %s vs %s" % (list(g.scfsi), o["scfsi"]))
+            if g.main_bytes != o["main_bytes"]:
+                diffs.append("main_bytes %d vs %d" % (g.main_bytes, o["main_bytes"]))
+            if diffs and good:
+                print("K6 allocator first mismatch stream %d frame %d:\n   " % (s, f) + "\n   ".join(diffs))
+                good = False
+    print("K6 allocator", "OK" if good else "MISMATCH")
+    ok &= good
+    nbad = 0
+    for s in range(S):
+        if gbytes[s] != obytes[s]:
+            nbad += 1
+            n = min(len(gbytes[s]), len(obytes[s]))
+            d = [i for i in range(n) if gbytes[s][i] != obytes[s][i]]
+            print("stream %d bytes differ: len %d vs %d first diff at %s" % (s, len(gbytes[s]), len(obytes[s]), d[:3]))
+    print("bitstream: %d/%d streams byte-identical to the oracle" % (S - nbad, S))
+    ok &= nbad == 0
+    print("RESULT", "PASS" if ok else "FAIL")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
