@@ -56,6 +56,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("hmp3_amd/libhmp3amd.so is missing - build it with hmp3_amd/build.sh "
                                "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64, and whichever copy is
+        # mapped first serves both.  Import torch (when present) before our library so that tensors
+        # and our kernels share a runtime; without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.hx_last_error.restype = C.c_char_p
         L.hx_default_control.argtypes = [C.POINTER(EControl)]

@@ -17,7 +17,7 @@ float hxo_quant_off[32];            /* l3math.c:81-114 rounding offsets minus 0.
 float hxo_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 uint32_t hxo_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-void hxo_math_init(void)
+__attribute__((constructor)) void hxo_math_init(void)
 {
     static const double q[32] = {
         0.09460, 0.02799, 0.01671, 0.01192, 0.00927, 0.00758, 0.00641, 0.00556, 0.00490, 0.00439, 0.00397,

@@ -1,0 +1,71 @@
+"""Host-side logic of the product and the C ABI surface.  CPU only: no compute call is made."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "hmp3_amd", "libhmp3amd.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="hmp3_amd/libhmp3amd.so not built (hmp3_amd/build.sh)")
+
+TABLES = ["psy_w", "psy_cnt", "psy_off", "psy_nsum", "psy_npart", "win", "csa", "m18_w", "m18_w2", "m18_c",
+          "look_gain", "look_34igain", "look_ix43", "look_log_cbwmb", "nBand_l", "startBand_l", "nsf", "taperNT",
+          "head", "ec", "scalars"]
+CONFIGS = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000),
+           dict(samprate=32000, bitrate=64), dict(bitrate=96, mode=0), dict(bitrate=160), dict(vbr_mnr=120, quick=0)]
+
+
+def test_library_exports_every_declared_symbol():
+    from hmp3_amd import api
+    hdr = open(os.path.join(ROOT, "include", "hmp3_amd.h")).read()
+    declared = set(re.findall(r"\b(hx_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = C.CDLL(LIB)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "include/hmp3_amd.h declares %s but the library does not export it" % name
+    assert set(api.EXPORTS) <= declared
+
+
+@pytest.mark.parametrize("kw", CONFIGS, ids=[str(i) for i in range(len(CONFIGS))])
+def test_host_tables_equal_oracle_tables(kw):
+    from hmp3_amd import api
+    l = O.lib()
+    l.hxo_debug_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_longlong]
+    l.hxo_debug_table.restype = C.c_longlong
+    eo = O.OracleEncoder(O.default_control(**kw))
+    eg = api.default_control(**kw)
+    for n in TABLES:
+        a = np.zeros(16384, np.uint8); b = np.zeros(16384, np.uint8)
+        na = l.hxo_debug_table(eo.h, n.encode(), a.ctypes.data, a.nbytes)
+        nb = api.lib().hx_debug_host_table(C.byref(eg), n.encode(), b.ctypes.data, b.nbytes)
+        assert na == nb and na > 0, n
+        assert np.array_equal(a[:na], b[:nb]), "table %s differs from the oracle's" % n
+
+
+def test_resolve_rejects_what_reference_rejects_and_out_of_scope():
+    from hmp3_amd import api
+    buf = np.zeros(64, np.uint8)
+
+    def ok(**kw):
+        return api.lib().hx_debug_host_table(C.byref(api.default_control(**kw)), b"scalars", buf.ctypes.data, 64) > 0
+    assert ok(bitrate=64) and ok() and ok(bitrate=48)
+    assert not ok(bitrate=40)               # mp3enc.cpp:346-351
+    assert not ok(bitrate=64, layer=2)      # mp3enc.cpp:388
+    assert not ok(bitrate=64, mode=3)       # mono: documented out of scope
+    assert not ok(bitrate=32, samprate=22050)   # MPEG-2: documented out of scope
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """on a box without a GPU the create call must fail (no silent CPU path)"""
+    import torch
+    from hmp3_amd import api
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        api.Batch(api.default_control(bitrate=64), nstreams=2, max_frames=2)
+    e = api.Mp3Enc()
+    assert e.L3_audio_encode_init(api.default_control(bitrate=64)) == 0

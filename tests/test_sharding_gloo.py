@@ -1,0 +1,56 @@
+"""Multi-process path of bench.py / multi-GPU runs on CPU: world_size 2, gloo.  Streams are
+sharded over ranks with no data-path collective; only the timing uses a max-reduce."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hmp3_amd import shard
+
+
+def test_shard_ranges_partition_the_streams():
+    for n in (1, 2, 7, 1024, 32768, 1000):
+        for w in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(w):
+                a, b = shard.shard_range(n, w, r)
+                seen += list(range(a, b))
+            assert seen == list(range(n))
+            if n >= w:
+                sizes = [shard.shard_range(n, w, r)[1] - shard.shard_range(n, w, r)[0] for r in range(w)]
+                assert max(sizes) - min(sizes) <= 1
+    assert shard.owner_of(5, 8, 2) == 1
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from hmp3_amd import synth
+    n, nfr = 6, 6
+    a, b = shard.shard_range(n, world, rank)
+    sizes = torch.zeros(n, dtype=torch.int64)
+    for s in range(a, b):       # each rank encodes only its own streams (oracle stands in for the GPU path)
+        enc = O.OracleEncoder(O.default_control(bitrate=64, short_block_threshold=99999))
+        sizes[s] = len(O.encode_stream(enc, synth.stream_pcm(s, nfr)))
+    dist.barrier()
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)        # bench.py: max over ranks of the timed region
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)    # test-only gather of the results
+    if rank == 0:
+        ret["tmax"] = float(t.item())
+        ret["sizes"] = sizes.tolist()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_cover_all_streams_once():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["tmax"] == 1.5
+    assert all(v > 0 for v in ret["sizes"]) and len(ret["sizes"]) == 6
