@@ -84,7 +84,7 @@ typedef struct {
     /* quantiser lookups (bitallo3.cpp:366-375) */
     float look_gain[128], look_34igain[128], look_ix43[256];
     /* short-block allocator init (bitallos.cpp:128-200) */
-    int nsfs, nbmax_s;
+    int nsfs, nbmax_s, look_log_cbwmb_s[16];
 } hxo_params;
 
 typedef struct {

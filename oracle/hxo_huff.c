@@ -45,6 +45,16 @@ static int pair_len(int t, int x, int y)
     return n;
 }
 
+/* shared with the short-block counter (hxo_short.c) */
+void hxo_huff_candidates(int rmax, int *ncand, int t[4], int *tmax)
+{
+    cand_t c;
+    candidates(rmax, &c);
+    *ncand = c.ncand; *tmax = c.tmax;
+    t[0] = c.t[0]; t[1] = c.t[1]; t[2] = c.t[2]; t[3] = c.t[3];
+}
+int hxo_huff_pair_len(int t, int x, int y) { return pair_len(t, x, y); }
+
 /* cnt.c:96-288: sum the candidates' lengths over a region, pick the shortest; ties go to the
    higher candidate index.  Returns bits, *index = chosen candidate. */
 static int count_region(const cand_t *c, const int *ix, int n, int *index)

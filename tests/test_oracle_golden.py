@@ -12,7 +12,7 @@ from hmp3_amd import synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 META = json.load(open(os.path.join(GOLD, "streams.json")))
-LONG_CASES = [k for k in META if k.endswith("_long")]
+ALL_CASES = list(META)      # long-only and default (block switching) configurations
 
 
 def test_known_answers_mblog_mbexp_pow34():
@@ -66,7 +66,7 @@ def test_stage_polyphase_hybrid_attack_bit_exact():
         prev = 1 if m > 700 else 0
 
 
-@pytest.mark.parametrize("name", LONG_CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_stream_bytes_and_sizes_match_reference(name):
     m = META[name]
     pcm = synth.stream_pcm(m["stream_seed"], m["frames"], sr=m["samprate"], rho=m["rho"], bursts=m["bursts"])

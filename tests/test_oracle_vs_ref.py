@@ -34,6 +34,25 @@ def test_long_block_streams_byte_identical(name, kw, sr, rho, nfr):
     assert len(a) > 0 and a == b
 
 
+SHORT_CASES = [
+    ("cbr128_bursts", dict(bitrate=64), 44100, 0.7, 160),
+    ("cbr128_lr_bursts", dict(bitrate=64, mode=0), 44100, 0.3, 100),
+    ("vbr50_bursts", dict(), 44100, 0.7, 160),
+    ("vbr100_hf2_48k_bursts", dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), 48000, 0.7, 120),
+    ("cbr128_32k_bursts", dict(bitrate=64, samprate=32000), 32000, 0.0, 100),
+    ("vbr50_thr100_mostly_short", dict(short_block_threshold=100), 44100, 0.7, 100),
+    ("cbr128_thr0_all_short", dict(bitrate=64, short_block_threshold=0), 44100, 1.0, 60),
+]
+
+
+@pytest.mark.parametrize("name,kw,sr,rho,nfr", SHORT_CASES, ids=[c[0] for c in SHORT_CASES])
+def test_block_switching_streams_byte_identical(name, kw, sr, rho, nfr):
+    pcm = synth.stream_pcm(13, nfr, sr=sr, rho=rho, bursts=True)
+    a = O.encode_stream(O.RefEncoder(O.default_control(**kw)), pcm)
+    b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+    assert len(a) > 0 and a == b
+
+
 def test_carried_state_matches_every_frame():
     kw = dict(bitrate=64, short_block_threshold=99999)
     pcm = synth.stream_pcm(3, 40)
