@@ -32,16 +32,28 @@ struct AllocLds {
     int mblog[256];
     float pow34_exp[256], pow34_a[16], pow34_b[16], quant_off[32];
     int logsub[84];
-    unsigned short huff_code[1408];
-    unsigned char huff_len[1408];
+    unsigned char huff_len[1408];       // codes stay in global memory (read once per pair when packing)
+    unsigned char sband_of_line[192];
+    int nBand_s[16], startBand_s[16], logcbw_s[16];
     unsigned short huff_off[32];
     unsigned char huff_dim[32], huff_lin[32], quada_code[16], quada_len[16];
     int nBand[NB], startBand[24], logcbw[NB], taper[NB];
-    // per band working set, [channel][sfb]
-    int snr[2][NB], Noise0[2][NB], Noise[2][NB], NT[2][NB], NTadjust[2][NB];
-    int gzero[2][NB], gmin[2][NB], gsf[2][NB], sf[2][NB], active[2][NB];
-    int ixmax[2][NB], ix10xmax[2][NB], up[2][NB], lo[2][NB], geval[2][NB], maskmb[2][NB];
-    float xsxx[2][NB], xsxxms[2][NB], x34max[2][NB];
+    int NTadjust[2][NB];                // long-block gain estimator feedback (persists)
+    union {
+        struct {    // long blocks: per band working set, [channel][sfb]
+            int snr[2][NB], Noise0[2][NB], Noise[2][NB], NT[2][NB];
+            int gzero[2][NB], gmin[2][NB], gsf[2][NB], sf[2][NB], active[2][NB];
+            int ixmax[2][NB], ix10xmax[2][NB], up[2][NB], lo[2][NB], geval[2][NB], maskmb[2][NB];
+            float xsxx[2][NB], xsxxms[2][NB], x34max[2][NB];
+        };
+        struct {    // short blocks: [channel][window][sfb]
+            int s_snr[2][3][16], s_Noise0[2][3][16], s_Noise[2][3][16], s_NT[2][3][16];
+            int s_gzero[2][3][16], s_gmin[2][3][16], s_gsf[2][3][16], s_sf[2][3][16], s_active[2][3][16];
+            int s_ixmax[2][3][16], s_geval[3][16], s_tmpn[3][16], s_maskmb[2][3][16];
+            float s_xsxx[2][3][16], s_x34max[2][3][16];
+            int s_G[2][3], s_GG[2], s_subgain[2][3];
+        };
+    };
     // per channel
     int G[2], preemp[2], scale[2], huff_bits[2];
     int hs_table[2][4], hs_cbreg[2][3], hs_nbig[2], hs_nquads[2], hs_bits[2];
@@ -58,6 +70,7 @@ struct AllocLds {
     unsigned int bitw[640];
     HxGr gr[2][2];
     int sfout[2][2][NB];
+    int sfs[2][3][12];                  // short-block scalefactors of the current granule
 };
 
 #define LANE ((int) threadIdx.x)
@@ -703,4 +716,5 @@ __device__ int count_bits(AllocLds &L, const HxParams *p, const int *ncb)
 }
 
 #include "hx_alloc2.inc"
+#include "hx_alloc_short.inc"
 #include "hx_alloc3.inc"

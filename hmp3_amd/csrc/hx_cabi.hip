@@ -18,17 +18,17 @@ __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream 
 __global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total);
 __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
                              int *dbg_metric, int NG, int total);
-__global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, int NG, int S, int *status);
+__global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
 __global__ void k_mdct(const float *sb, const HxStream *st, const HxParams *prm, const unsigned char *bt,
                        float *xr, int NG, int SG, long long units);
 __global__ void k_psy(const float *xr, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
-                      float *etab, float *thr, int NG);
+                      float *etab, float *thr, const unsigned char *bt, int NG);
 __global__ void k_msmetric(const float *xr, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
-                           int *msbase, int NG);
+                           int *msbase, const unsigned char *bt, int NG);
 __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S);
 struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
-    const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt;
+    const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
     unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status;
 };
 __global__ void k_alloc(AllocArgs a);
@@ -52,7 +52,7 @@ struct hx_batch {
     HxStream *d_st = nullptr;
     float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
-    unsigned char *d_flg = nullptr, *d_bt = nullptr;
+    unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
     HxFrameDebug *d_dbg = nullptr;
     int lastNG = 0;                     // NG of the previous call (layout of the carry)
     bool debug = false;
@@ -81,7 +81,7 @@ extern "C" void hx_batch_destroy(hx_batch *b)
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
-                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes};
+                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &pr : b->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete b;
@@ -132,6 +132,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_msbase, sizeof(int) * S * NG);
     ALLOC(b->d_flg, S * NG);
     ALLOC(b->d_bt, S * NG);
+    ALLOC(b->d_btprev, S);
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
     HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
@@ -185,14 +186,14 @@ extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int
     tot = S * NG;
     hipLaunchKernelGGL(k_attack_flg, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
                        b->debug ? b->d_dbgmetric : nullptr, NG, tot);
-    hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, b->d_bt, NG, S, b->d_status);
+    hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, b->d_bt, b->d_btprev, NG, S);
     long long units = (long long) S * NG * 2;
     hipLaunchKernelGGL(k_mdct, dim3((unsigned) ((units + 1) / 2)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_bt, b->d_xr, NG, SG, units);
-    hipLaunchKernelGGL(k_psy, dim3((unsigned) units), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_etab, b->d_thr, NG);
-    hipLaunchKernelGGL(k_msmetric, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_msbase, NG);
+    hipLaunchKernelGGL(k_psy, dim3((unsigned) units), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_etab, b->d_thr, b->d_bt, NG);
+    hipLaunchKernelGGL(k_msmetric, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_msbase, b->d_bt, NG);
     AllocArgs a;
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
-    a.msbase = b->d_msbase; a.bt = b->d_bt; a.out = d_out; a.out_bytes = d_out_bytes;
+    a.msbase = b->d_msbase; a.bt = b->d_bt; a.btprev = b->d_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));

@@ -176,21 +176,21 @@ __global__ void k_attack_flg(const HxStream *__restrict__ st, const HxParams *__
 
 // serial per stream: block_type[g] = table[prev type][short now][short next]
 __global__ void k_blocktype(HxStream *__restrict__ st, const unsigned char *__restrict__ flg,
-                            const int *__restrict__ eng, unsigned char *__restrict__ bt, int NG, int S,
-                            int *__restrict__ status)
+                            const int *__restrict__ eng, unsigned char *__restrict__ bt,
+                            unsigned char *__restrict__ btprev, int NG, int S)
 {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const unsigned char sel[16] = {0, 1, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 0, 1, 2, 2};
     HxStream *ss = st + s;
     int prev_next = ss->short_flag_next_prev, prev_bt = ss->bt_prev;
+    btprev[s] = (unsigned char) prev_bt;
     for (int g = 0; g < NG; g++) {
         int f = flg[(long long) s * NG + g];
         int next = prev_next ? (f >> 1) & 1 : f & 1;
         int cur = prev_next;
         int b = sel[prev_bt * 4 + cur * 2 + next];
         bt[(long long) s * NG + g] = (unsigned char) b;
-        if (b == 2) atomicOr(status, 1);        // short blocks: not on the GPU path yet
         prev_bt = b;
         prev_next = next;
     }
@@ -270,6 +270,41 @@ __device__ __forceinline__ void mdct18(const HxParams *p, const float *f, float 
     y[17] = y[17] - y[16];
 }
 
+// three 6-point transforms of a short block (reference emdct.c:252-303); y[6*w + k]
+__device__ __forceinline__ void mdct6x3(const HxParams *p, const float *f, float *y)
+{
+    const float *v = p->m6_v, *v2 = p->m6_v2;
+    const float c87 = p->m6_c87;
+    float a[18];
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float g1 = v[q] * f[6 * w + q];
+            float g2 = v[5 - q] * f[6 * w + 5 - q];
+            a[6 * w + q] = g1 + g2;
+            a[6 * w + 3 + q] = v2[q] * (g1 - g2);
+        }
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const float *aa = a + 6 * w;
+        float *c = y + 6 * w;
+        float a02 = (aa[0] + aa[2]);
+        float b02 = (aa[3] + aa[5]);
+        c[0] = a02 + aa[1];
+        c[1] = b02 + aa[4];
+        c[2] = c87 * (aa[0] - aa[2]);
+        c[3] = c87 * (aa[3] - aa[5]) - c[1];
+        c[1] = c[1] - c[0];
+        c[2] = c[2] - c[1];
+        c[4] = a02 - aa[1] - aa[1];
+        c[5] = b02 - aa[4] - aa[4] - c[3];
+        c[3] = c[3] - c[2];
+        c[4] = c[4] - c[3];
+        c[5] = c[5] - c[4];
+    }
+}
+
 // One lane = one subband of one (stream, channel, granule); 2 granule-channels per wave.
 // Frequency inversion (hwin.c:282) is applied while reading, so the stored subband samples
 // stay un-inverted; the alias butterflies exchange 8 values with each neighbour lane.
@@ -301,13 +336,27 @@ __global__ __launch_bounds__(64) void k_mdct(const float *__restrict__ sb, const
             if (inv && (i & 1)) { a = -a; b = -b; }
             p1[i] = a; p2[i] = b;
         }
-        const float *w = p->win[btype == 2 ? 0 : btype];
+        if (btype != 2) {
+            const float *w = p->win[btype];
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            f[j] = w[26 - j] * p2[8 - j] + w[27 + j] * p2[9 + j];
-            f[9 + j] = w[j] * p1[j] + w[17 - j] * p1[17 - j];
+            for (int j = 0; j < 9; j++) {
+                f[j] = w[26 - j] * p2[8 - j] + w[27 + j] * p2[9 + j];
+                f[9 + j] = w[j] * p1[j] + w[17 - j] * p1[17 - j];
+            }
+            mdct18(p, f, y);
+        } else {        // short: three overlapping 12-tap windows (reference hwin.c:228-278)
+            const float *w = p->win[2];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                f[q] = w[8 - q] * p1[14 - q] + w[9 + q] * p1[15 + q];
+                f[3 + q] = w[q] * p1[6 + q] + w[5 - q] * p1[11 - q];
+                f[6 + q] = w[8 - q] * p2[2 - q] + w[9 + q] * p2[3 + q];
+                f[9 + q] = w[q] * p1[12 + q] + w[5 - q] * p1[17 - q];
+                f[12 + q] = w[8 - q] * p2[8 - q] + w[9 + q] * p2[9 + q];
+                f[15 + q] = w[q] * p2[q] + w[5 - q] * p2[5 - q];
+            }
+            mdct6x3(p, f, y);
         }
-        mdct18(p, f, y);
     } else {
 #pragma unroll
         for (int i = 0; i < 18; i++) y[i] = 0.0f;
@@ -320,16 +369,26 @@ __global__ __launch_bounds__(64) void k_mdct(const float *__restrict__ sb, const
         float cs = p->csa[0][i], ca = p->csa[1][i];
         float a = y[17 - i], b = y[i];
         float na = a, nb = b;
-        if (sbnd < nsb - 1) na = a * cs + up * ca;      // upper edge of this band
-        else if (sbnd == nsb - 1) na = a * cs;          // last coded band: half butterfly
-        if (sbnd >= 1 && sbnd < nsb) nb = b * cs - dn * ca;     // lower edge (pairs with band-1)
+        if (btype != 2) {                                   // no alias reduction on short blocks
+            if (sbnd < nsb - 1) na = a * cs + up * ca;      // upper edge of this band
+            else if (sbnd == nsb - 1) na = a * cs;          // last coded band: half butterfly
+            if (sbnd >= 1 && sbnd < nsb) nb = b * cs - dn * ca;     // lower edge (pairs with band-1)
+        }
         y[17 - i] = na;
         y[i] = nb;
     }
     if (live) {
-        float *o = xr + ((sg * 2 + ch) * 576) + sbnd * 18;
+        if (btype != 2) {
+            float *o = xr + ((sg * 2 + ch) * 576) + sbnd * 18;
 #pragma unroll
-        for (int i = 0; i < 18; i++) o[i] = y[i];
+            for (int i = 0; i < 18; i++) o[i] = y[i];
+        } else {                                            // [3 windows][192], line = 6*sb + k
+            float *o = xr + ((sg * 2 + ch) * 576) + sbnd * 6;
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) o[192 * w + k] = y[6 * w + k];
+        }
     }
 }
 
@@ -337,15 +396,50 @@ __global__ __launch_bounds__(64) void k_mdct(const float *__restrict__ sb, const
 // Outputs etab (energy + absolute threshold) and thr = a * stab (threshold before pre-echo control).
 __global__ __launch_bounds__(64) void k_psy(const float *__restrict__ xr, const HxStream *__restrict__ st,
                                             const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
-                                            float *__restrict__ etab_out, float *__restrict__ thr_out, int NG)
+                                            float *__restrict__ etab_out, float *__restrict__ thr_out,
+                                            const unsigned char *__restrict__ bt, int NG)
 {
     __shared__ float xtab[64];
+    __shared__ float es[3][64];
     const int lane = threadIdx.x;
     const long long u = blockIdx.x;             // (s, g, ch)
     const int s = (int) ((u >> 1) / NG);
     const HxParams *p = prm + st[s].cls;
     const HxPsyTab *pt = &p->psyL;
     const float *x = xr + u * 576;
+    if (bt[u >> 1] == 2) {
+        // short block (reference emap.c:61-93, spdsmr.c:64-107): per-window partition energies,
+        // then mask[w][sfb] = spread(2 sfb partitions); pre-echo control happens in the allocator
+        const HxPsyTab *ps = &p->psyS;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+        if (lane < ps->npart_e) {
+            int i0 = ps->pstart[lane], n = ps->nsum[lane];
+            for (int k = 0; k < n; k++) {
+                s0 += x[i0 + k] * x[i0 + k];
+                s1 += x[192 + i0 + k] * x[192 + i0 + k];
+                s2 += x[384 + i0 + k] * x[384 + i0 + k];
+            }
+        }
+        es[0][lane] = s0; es[1][lane] = s1; es[2][lane] = s2;
+        __syncthreads();
+        float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+        if (lane < 12 && 2 * lane < ps->npart) {
+            float a[3] = {0.5f, 0.5f, 0.5f}, b[3] = {0.5f, 0.5f, 0.5f};
+            int i = 2 * lane, q = ps->off[i], n = ps->cnt[i], r = ps->row[i];
+            for (int j = 0; j < n; j++)
+                for (int w = 0; w < 3; w++) a[w] += ps->w[r + j] * es[w][q + j];
+            q = ps->off[i + 1]; n = ps->cnt[i + 1]; r = ps->row[i + 1];
+            for (int j = 0; j < n; j++)
+                for (int w = 0; w < 3; w++) b[w] += ps->w[r + j] * es[w][q + j];
+            m0 = a[0] + b[0]; m1 = a[1] + b[1]; m2 = a[2] + b[2];
+        }
+        etab_out[u * 64 + lane] = 0.0f;
+        float v = 0.0f;
+        // thr layout for short granules: [12*w + sfb]
+        if (lane < 12) { thr_out[u * 64 + lane] = m0; thr_out[u * 64 + 12 + lane] = m1; thr_out[u * 64 + 24 + lane] = m2; }
+        else if (lane >= 36) thr_out[u * 64 + lane] = v;
+        return;
+    }
     const float *w = pt->w;
     const float alpha = 0.30f;
     const int npart = pt->npart, npart2 = (npart + 1) & (~1);
@@ -401,7 +495,7 @@ __global__ __launch_bounds__(64) void k_psy(const float *__restrict__ xr, const 
 // M/S decision metric before hysteresis: lane = scalefactor band (reference bitallo3.cpp:695-742)
 __global__ __launch_bounds__(64) void k_msmetric(const float *__restrict__ xr, const HxStream *__restrict__ st,
                                                  const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
-                                                 int *__restrict__ msbase, int NG)
+                                                 int *__restrict__ msbase, const unsigned char *__restrict__ bt, int NG)
 {
     const int lane = threadIdx.x;
     const long long sg = blockIdx.x;            // (s, g)
@@ -409,6 +503,25 @@ __global__ __launch_bounds__(64) void k_msmetric(const float *__restrict__ xr, c
     const HxParams *p = prm + st[s].cls;
     const float *x0 = xr + sg * 1152, *x1 = x0 + 576;
     int v = 0;
+    if (bt[sg] == 2) {      // short block (reference bitallos.cpp:377-416): lane = (window, sfb)
+        const int w = lane >> 4, i = lane & 15;
+        int d = 0;
+        if (w < 3 && i < p->nsfs) {
+            int k = 192 * w + p->startBand_s[i], n = p->nBand_s[i];
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int j = 0; j < n; j++, k++) {
+                float a = x0[k] * x0[k], b = x1[k] * x1[k];
+                s0 += (a + b);
+                a = fabsf(a - b);
+                s1 += a;
+            }
+            if ((double) s1 > 0.80 * (double) s0) d++;
+            if ((double) s1 > 0.95 * (double) s0) d += 2;
+        }
+        d = hx_wave_sum(d);
+        if (lane == 0) msbase[sg] = (p->nsfs - d) << 10;
+        return;
+    }
     if (lane < p->nsf[0]) {
         int k = p->startBand_l[lane], n = p->nBand_l[lane];
         float el = 100.0f, er = 100.0f, t = 0.0f;

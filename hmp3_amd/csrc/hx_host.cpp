@@ -211,6 +211,71 @@ static void psy_long_tables(HxParams *p)
     pt->pstart[64] = t;
 }
 
+// Painter & Spanias / Schroeder spreading, short blocks (amodini2.c:173-196)
+static float spread_short(float bz0, float bz)
+{
+    double a = 0.2302585093, x, y;
+    x = (bz0 - bz) * 1.00;
+    x += 0.474;
+    y = 15.811389 + 7.5 * x - 17.5 * sqrt(1.0 + x * x);
+    if (y <= -60.0) return 0.0f;
+    return (float) exp(y * a);
+}
+
+// amod_initShort (amodini2.c:587-739): 2 partitions per short sfb on the 192-line window
+static void psy_short_tables(HxParams *p)
+{
+    static const float dbsnr[][2] = {
+        {0.0f, 12.0f}, {861.0f, 10.0f}, {2584.0f, 8.0f}, {5857.0f, 7.0f}, {9302.0f, 5.0f},
+        {13092.0f, 4.0f}, {15500.0f, 3.0f}, {99999.0f, -2.0f}};
+    HxPsyTab *pt = &p->psyS;
+    int part[32], t = 0, npart, ntot = 0, i;
+    float snr_factor[32], bval[32], s[64];
+    memset(pt, 0, sizeof(*pt));
+    for (i = 0; i < 32; i++) part[i] = 192;
+    for (i = 0; i < 14; i++) {
+        int nb = (i < 13) ? p->nBand_s[i] : 0, m = nb / 2;
+        part[2 * i] = t; t += m;
+        part[2 * i + 1] = t; t += nb - m;
+    }
+    int nbin = 6 * p->nsb_limit;
+    for (npart = 0; npart < 32; npart++) if (part[npart] >= nbin) break;
+    if (npart > 24) npart = 24;
+    float x = 0.5f * p->samprate / 192;
+    for (i = 0; i < 31; i++) {
+        float freq = x * 0.5f * (part[i] + part[i + 1]);
+        snr_factor[i] = (float) (0.7 * pow(10.0, -0.1 * interp(dbsnr, freq)));
+        bval[i] = f_to_bark(freq);
+    }
+    snr_factor[i] = 1.0f;
+    bval[i] = bval[i - 1];
+    float *w = pt->w;
+    for (i = 0; i < npart; i++) {
+        int j, count = 0, nj;
+        for (j = 0; j < 64; j++) s[j] = 0.0f;
+        for (j = 0; j < npart; j++) s[j] = spread_short(bval[i], bval[j]);
+        for (j = 0; j < npart; j++) { if (s[j] > 1.0e-6f) break; s[j] = 0.0f; }
+        for (; j < npart; j++) if (s[j] <= 1.0e-6f) break;
+        for (; j < npart; j++) s[j] = 0.0f;
+        for (j = 0; j < npart; j++) if (s[j] != 0.0f) break;
+        nj = j;
+        if (nj >= npart) break;
+        pt->row[i] = ntot;
+        for (; j < npart; j++) {
+            if (s[j] == 0.0f) break;
+            count++; ntot++;
+            *w++ = 0.35f * snr_factor[i] * s[j];
+        }
+        pt->cnt[i] = count;
+        pt->off[i] = nj;
+    }
+    pt->npart = i;
+    for (i = 0; i < npart; i++) pt->nsum[i] = part[i + 1] - part[i];
+    pt->npart_e = npart;
+    for (i = 0, t = 0; i < 64; i++) { pt->pstart[i] = t; t += pt->nsum[i]; }
+    pt->pstart[64] = t;
+}
+
 // Returns 0 when the configuration is outside what the MI355X path implements (the reference
 // would run MPEG-2, mono, dual-channel or intensity stereo there) or when the reference itself
 // rejects it (mp3enc.cpp:346-351,388); 9216 (bytes of float PCM per frame) otherwise.
@@ -320,6 +385,7 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     for (int i = 0; i < 13; i++) p->nBand_s[i] = sfb_short[p->sr_index][i + 1] - sfb_short[p->sr_index][i];
     transform_tables(p);
     psy_long_tables(p);
+    psy_short_tables(p);
 
     int is_flag = 0;
     p->ms_flag = 0;
@@ -362,6 +428,18 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     k = 0;
     for (int i = 0; i < 13; i++) { p->startBand_s[i] = k; k += p->nBand_s[i]; }
     p->startBand_s[13] = k;
+    {   // CBitAlloShort::BitAlloInit (bitallos.cpp:128-200): limits arrive in long-block lines
+        int bl = p->band_limit / 3 - 10, i;
+        for (i = 0; i < 14; i++) if (bl <= sfb_short[p->sr_index][i]) break;
+        p->nsfs = i > 12 ? 12 : i;
+        p->nbmax_s = p->startBand_s[p->nsfs];
+        for (i = 0; i < 12; i++) p->look_log_cbwmb_s[i] = (int) (100.0f * (float) (10.0 * log10((double) (float) p->nBand_s[i])));
+        for (i = 0; i < 192; i++) {
+            int b = 12;
+            for (int j = 0; j < 13; j++) if (i < p->startBand_s[j + 1]) { b = j; break; }
+            p->sband_of_line[i] = (unsigned char) b;
+        }
+    }
     for (int j = 0; j < 2; j++) p->nbmax3[j] = p->nbmax2[j] = p->nbmax[j] = p->startBand_l[p->nsf[j]];
     if (p->hf_flag) p->nbmax2[0] = p->startBand_l[p->nsf2[0]];
     if (p->hf_flag & 2) { p->nbmax3[0] = p->startBand_l[p->nsf3[0]]; p->nbmax3[1] = p->startBand_l[p->nsf3[1]]; }

@@ -52,7 +52,11 @@ struct HxParams {
     float m18_w[18], m18_w2[9], m18_c[9][4];
     float m6_v[6], m6_v2[3], m6_c87;
     HxPsyTab psyL;
+    HxPsyTab psyS;                      // short blocks: rows from w[0]
     float look_gain[128], look_34igain[128], look_ix43[256];
+    // short-block allocator (reference bitallos.cpp:128-200)
+    int nsfs, nbmax_s, look_log_cbwmb_s[16];
+    unsigned char sband_of_line[192];   // short sfb index of each line of a 192-line window
 };
 
 // Class-independent tables.

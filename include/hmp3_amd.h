@@ -86,8 +86,8 @@ int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, u
 /* same with host buffers (staged through the device, synchronous) */
 int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out,
                              long long out_stride, int *out_bytes);
-/* status bits accumulated by the kernels: 1 = a short block was selected (not on the GPU path
-   yet), 2 = main data overflow (the reference would assert).  Synchronises. */
+/* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
+   there).  0 = healthy.  Synchronises. */
 int hx_batch_status(hx_batch *b);
 /* total frames / bytes emitted so far by stream i (synchronises) */
 HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int stream_index);

@@ -26,7 +26,19 @@ CONFIGS = {
     "vbr100_hf2_48k": dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000, short_block_threshold=99999),
     "cbr128_32k": dict(bitrate=64, samprate=32000, short_block_threshold=99999),
     "cbr128_48k": dict(bitrate=64, samprate=48000, short_block_threshold=99999),
+    # block switching enabled (CLI default threshold 700); the signal carries noise bursts
+    "cbr128_sw": dict(bitrate=64),
+    "cbr128_lr_sw": dict(bitrate=64, mode=0),
+    "vbr50_sw": dict(),
+    "vbr100_hf2_48k_sw": dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000),
+    "cbr128_32k_sw": dict(bitrate=64, samprate=32000),
+    "vbr50_thr100_mostly_short": dict(short_block_threshold=100),
+    "cbr128_thr0_all_short": dict(bitrate=64, short_block_threshold=0),
 }
+
+
+def wants_bursts(kw):
+    return kw.get("short_block_threshold", 700) < 99999
 
 
 def api():
@@ -48,18 +60,22 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
     kw = CONFIGS[name]
     sr = kw.get("samprate", 44100)
     S, F = 12, 48
-    pcm = np.stack([synth.stream_pcm(100 + i, F, sr=sr, rho=RHOS[i % 4]) for i in range(S)])
+    pcm = np.stack([synth.stream_pcm(100 + i, F, sr=sr, rho=RHOS[i % 4], bursts=wants_bursts(kw)) for i in range(S)])
     b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
     got = b.encode_host(pcm)
     assert b.status() == 0
     for s in range(S):
         assert got[s] == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    if wants_bursts(kw):        # the case really exercises short blocks
+        bt = b.debug_read("bt", np.uint8, S * 2 * F)
+        assert (bt == 2).sum() > 0 and (bt == 1).sum() > 0 and (bt == 3).sum() > 0
     fb = [b.frames_bytes(s) for s in range(S)]
     assert all(f[1] == len(got[i]) for i, f in enumerate(fb))
     b.close()
 
 
-@pytest.mark.parametrize("name", ["cbr128_long", "vbr50_long", "vbr100_hf2_48k_long", "cbr128_32k_long"])
+@pytest.mark.parametrize("name", ["cbr128_long", "vbr50_long", "vbr100_hf2_48k_long", "cbr128_32k_long",
+                                  "cbr128_default_bursts", "vbr50_default_bursts"])
 def test_golden_reference_streams(name):
     """committed reference bitstreams (tests/golden, captured from the real reference)"""
     m = META[name]
@@ -120,9 +136,9 @@ def test_every_stage_bit_exact():
 
 def test_ragged_calls_equal_one_shot():
     """state carry across calls: 1 + 7 + 24 frames in three calls == 32 frames in one call"""
-    kw = CONFIGS["vbr50"]
+    kw = CONFIGS["vbr50_sw"]       # block switching on: the carry includes detector and block-type state
     S, F = 5, 32
-    pcm = np.stack([synth.stream_pcm(300 + i, F, rho=RHOS[i % 4]) for i in range(S)])
+    pcm = np.stack([synth.stream_pcm(300 + i, F, rho=RHOS[i % 4], bursts=True) for i in range(S)])
     one = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
     ref = one.encode_host(pcm)
     one.close()
@@ -141,10 +157,10 @@ def test_ragged_calls_equal_one_shot():
 def test_mixed_configuration_classes_in_one_batch():
     """per-stream E_CONTROL: 32 / 44.1 / 48 kHz and CBR / VBR side by side (config 5 style)"""
     a = api()
-    kws = [dict(bitrate=64, samprate=32000), dict(bitrate=64), dict(bitrate=64, samprate=48000), dict(), dict(bitrate=96, mode=0)]
-    kws = [dict(k, short_block_threshold=99999) for k in kws]
+    kws = [dict(bitrate=64, samprate=32000), dict(bitrate=64), dict(bitrate=64, samprate=48000), dict(),
+           dict(bitrate=96, mode=0, short_block_threshold=99999)]
     S, F = 10, 24
-    pcm = np.stack([synth.stream_pcm(400 + i, F, sr=kws[i % 5].get("samprate", 44100), rho=RHOS[i % 4]) for i in range(S)])
+    pcm = np.stack([synth.stream_pcm(400 + i, F, sr=kws[i % 5].get("samprate", 44100), rho=RHOS[i % 4], bursts=True) for i in range(S)])
     b = a.Batch([a.default_control(**kws[i % 5]) for i in range(S)], max_frames=F)
     got = b.encode_host(pcm)
     for s in range(S):
