@@ -20,7 +20,7 @@
 #define PART23 4021
 #define NB 22
 
-struct AllocLds {
+struct alignas(16) AllocLds {
     float xr[2][576];
     float x34[2][576];
     float term[2][576];
@@ -32,7 +32,8 @@ struct AllocLds {
     int mblog[256];
     float pow34_exp[256], pow34_a[16], pow34_b[16], quant_off[32];
     int logsub[84];
-    unsigned char huff_len[1408];       // codes stay in global memory (read once per pair when packing)
+    unsigned short huff_code[1408];
+    unsigned char huff_len[1408];
     unsigned char sband_of_line[192];
     int nBand_s[16], startBand_s[16], logcbw_s[16];
     unsigned short huff_off[32];
@@ -45,6 +46,8 @@ struct AllocLds {
             int gzero[2][NB], gmin[2][NB], gsf[2][NB], sf[2][NB], active[2][NB];
             int ixmax[2][NB], ix10xmax[2][NB], up[2][NB], lo[2][NB], geval[2][NB], maskmb[2][NB];
             float xsxx[2][NB], xsxxms[2][NB], x34max[2][NB];
+            float gig[2][NB], gg[2][NB];        // gain pair of the band's current evaluation step
+            int lucky[6][2][13];                // big_lucky_noise: noise of candidate c of band (ch, sfb)
         };
         struct {    // short blocks: [channel][window][sfb]
             int s_snr[2][3][16], s_Noise0[2][3][16], s_Noise[2][3][16], s_NT[2][3][16];
@@ -68,13 +71,32 @@ struct AllocLds {
     int tmpn[2][NB];
     // bit staging for one frame's main data (MSB-first 32-bit words)
     unsigned int bitw[640];
+    unsigned int sidew[10];
     HxGr gr[2][2];
     int sfout[2][2][NB];
     int sfs[2][3][12];                  // short-block scalefactors of the current granule
+#ifdef HX_PROFILE
+    unsigned long long prof[32];
+#endif
 };
 
+#ifdef HX_PROFILE
+#define PROF(id, stmt) do { SYNC(); long long t0_ = clock64(); stmt; SYNC(); if (LANE == 0) L.prof[id] += (unsigned long long) (clock64() - t0_); } while (0)
+#define PROF_T0() long long tp_ = clock64()
+#define PROF_ACC(id) do { SYNC(); if (LANE == 0) L.prof[id] += (unsigned long long) (clock64() - tp_); tp_ = clock64(); } while (0)
+#else
+#define PROF(id, stmt) do { stmt; } while (0)
+#define PROF_T0() do { } while (0)
+#define PROF_ACC(id) do { } while (0)
+#endif
 #define LANE ((int) threadIdx.x)
-#define SYNC() __syncthreads()
+// The workgroup is a single wavefront, and a wave's LDS operations execute in issue order, so an
+// LDS hand-over between lanes only needs the compiler to keep the accesses in program order.
+// __syncthreads() would also drain every outstanding global load/store (s_waitcnt vmcnt(0)),
+// which costs a memory round trip per call in the frame-level code.  SYNC_G() is the full
+// barrier, used where lanes exchange data through global memory.
+#define SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define SYNC_G() __syncthreads()
 
 // ---------------------------------------------------------------------------------------
 // bit staging: OR an n-bit field (n <= 32) at absolute bit position pos
@@ -94,10 +116,36 @@ __device__ __forceinline__ void put_bits64(AllocLds &L, int pos, unsigned long l
 }
 
 // sequential (reference-order) sum of term[ch][start .. start+n)
+// Every scalefactor band starts on an even line and has an even width (ISO Table B.8), so the
+// terms are fetched as 8-byte pairs, four pairs in flight, and added strictly in line order.
 __device__ __forceinline__ float band_sum(const float *t, int n, float acc)
 {
-    for (int j = 0; j < n; j++) acc += t[j];
+    const float2 *t2 = reinterpret_cast<const float2 *>(t);
+    const int m = n >> 1;
+    int j = 0;
+    for (; j + 4 <= m; j += 4) {
+        float2 a = t2[j], b = t2[j + 1], c = t2[j + 2], d = t2[j + 3];
+        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
+        acc += c.x; acc += c.y; acc += d.x; acc += d.y;
+    }
+    for (; j < m; j++) { float2 a = t2[j]; acc += a.x; acc += a.y; }
     return acc;
+}
+// two independent sums over the same band of two term arrays (same order each)
+__device__ __forceinline__ void band_sum2(const float *t, const float *u, int n, float *s0, float *s1)
+{
+    const float2 *t2 = reinterpret_cast<const float2 *>(t), *u2 = reinterpret_cast<const float2 *>(u);
+    const int m = n >> 1;
+    float a0 = 0.0f, a1 = 0.0f;
+    int j = 0;
+    for (; j + 2 <= m; j += 2) {
+        float2 a = t2[j], b = t2[j + 1], c = u2[j], d = u2[j + 1];
+        a0 += a.x; a1 += c.x; a0 += a.y; a1 += c.y;
+        a0 += b.x; a1 += d.x; a0 += b.y; a1 += d.y;
+    }
+    for (; j < m; j++) { float2 a = t2[j], c = u2[j]; a0 += a.x; a1 += c.x; a0 += a.y; a1 += c.y; }
+    *s0 = a0;
+    *s1 = a1;
 }
 
 // x^(3/4): piecewise-linear mantissa fit x exponent table (reference pow34.c:132-154)
@@ -145,21 +193,73 @@ __device__ __forceinline__ int sf_upper(int scale, int pre, int i)
 // ---------------------------------------------------------------------------------------
 // Noise sweep: every band with geval >= 0 gets its quantisation noise (mB) measured at gain
 // step geval (reference l3math.c:512-541).  Result left in L.tmp-free per-band array `out`.
+// one line of a noise measurement: (x - gain * ix^(4/3))^2 for ix = round(igain * x34 - 0.0946)
+// (reference l3math.c:521-535).  *fast is false when ix falls outside the 256-entry table.
+__device__ __forceinline__ float noise_term(const AllocLds &L, float igain, float gain, float x34, float x, bool *fast)
+{
+    float tmp = (igain * x34 + (0.0f - 0.0946f));
+    const int qx = (int) (tmp + copysignf(0.5f, tmp));
+    *fast = (qx >= 0 && qx < 256);
+    const float xhat = gain * L.look_ix43[*fast ? qx : 0];
+    tmp = x - xhat;
+    return tmp * tmp;
+}
+__device__ __noinline__ float noise_term_slow(float igain, float gain, float x34, float x)
+{
+    float tmp = (igain * x34 + (0.0f - 0.0946f));
+    const int qx = (int) (tmp + copysignf(0.5f, tmp));
+    const float xhat = (float) (gain * pow((double) qx, (4.0 / 3.0)));
+    tmp = x - xhat;
+    return tmp * tmp;
+}
+
 __device__ void noise_sweep(AllocLds &L, const HxParams *p, int nlines0, int nlines1, int out[2][NB])
 {
+    // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
+    // and the line range that any evaluated band touches
+    int lo = 576, hi = 0;
+    {
+        const int bch = LANE >> 5, bi = LANE & 31;
+        if (bi < NB) {
+            const int g = L.geval[bch][bi];
+            L.gig[bch][bi] = (g >= 0) ? L.look_34igain[g] : -1.0f;
+            L.gg[bch][bi] = (g >= 0) ? L.look_gain[g] : 0.0f;
+            if (g >= 0) { lo = L.startBand[bi]; hi = lo + L.nBand[bi]; }
+        }
+        lo = -hx_wave_max(-lo);
+        hi = hx_wave_max(hi);
+    }
+    SYNC();
+    // Branch-free bodies, fully unrolled: the nine independent LDS chains of a lane overlap
+    // instead of paying the LDS latency nine times (one wave per SIMD has nothing else to run).
     for (int ch = 0; ch < 2; ch++) {
-        int nl = ch ? nlines1 : nlines0;
-        for (int j = LANE; j < nl; j += 64) {
-            int g = L.geval[ch][L.band_of_line[j]];
-            if (g >= 0) {
-                float igain = L.look_34igain[g], gain = L.look_gain[g];
-                float tmp = (igain * L.x34[ch][j] + (0.0f - 0.0946f));
-                int qx = (int) (tmp + copysignf(0.5f, tmp));
-                float xhat;
-                if (qx >= 0 && qx < 256) xhat = gain * L.look_ix43[qx];
-                else xhat = (float) (gain * pow((double) qx, (4.0 / 3.0)));
-                tmp = L.xr[ch][j] - xhat;
-                L.term[ch][j] = tmp * tmp;
+        const int nl = min(ch ? nlines1 : nlines0, hi);
+        if (lo >= nl) continue;
+        bool slow = false;
+        for (int j0 = lo + LANE; j0 - LANE < nl; j0 += 192) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int j = j0 + 64 * k;
+                const bool ok = j < nl;
+                const int jc = ok ? j : lo;
+                const int bnd = L.band_of_line[jc];
+                const float igain = L.gig[ch][bnd], gain = L.gg[ch][bnd];
+                bool fast;
+                const float t = noise_term(L, igain, gain, L.x34[ch][jc], L.xr[ch][jc], &fast);
+                const bool act = ok && igain >= 0.0f;
+                if (act && fast) L.term[ch][j] = t;
+                slow |= act && !fast;
+            }
+        }
+        if (__any(slow)) {      // values beyond the table: rare, recompute those lines with pow()
+            for (int j = lo + LANE; j < nl; j += 64) {
+                const int bnd = L.band_of_line[j];
+                const float igain = L.gig[ch][bnd];
+                bool fast;
+                if (igain >= 0.0f) {
+                    noise_term(L, igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j], &fast);
+                    if (!fast) L.term[ch][j] = noise_term_slow(igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j]);
+                }
             }
         }
     }
@@ -186,12 +286,7 @@ __device__ void adjust_nt(AllocLds &L, const HxParams *p)
     const bool sel = (i < nsf) && (L.snr[ch][i] > sth);
     // integer sums within each half-wave (channel)
     int na = sel ? 1 : 0, ab = sel ? L.nBand[i] * L.NT[ch][i] : 0, nab = sel ? L.nBand[i] : 0;
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        na += __shfl_xor(na, m, 64);
-        ab += __shfl_xor(ab, m, 64);
-        nab += __shfl_xor(nab, m, 64);
-    }
+    na = hx_half_sum(na); ab = hx_half_sum(ab); nab = hx_half_sum(nab);
     na += 1; nab += 1;
     ab = ab / nab;
     if (na >= 5 && sel) {
@@ -206,17 +301,22 @@ __device__ void adjust_nt(AllocLds &L, const HxParams *p)
 // x^(3/4) of the first nl lines, band maxima, gzero / gmin (reference bitallo3.cpp:878-896)
 __device__ void pow34_gzero(AllocLds &L, const HxParams *p, int nl0, int nl1, int nb0, int nb1)
 {
-    for (int ch = 0; ch < 2; ch++) {
-        int nl = ch ? nl1 : nl0;
-        for (int j = LANE; j < nl; j += 64) L.x34[ch][j] = pow34(L, L.xr[ch][j]);
+    const int ch = LANE >> 5, i = LANE & 31;
+    if (i < NB) L.x34max[ch][i] = 0.0f;
+    SYNC();
+    // band maximum: x^(3/4) >= 0, so the float order equals the order of the bit patterns
+    // (the reference's vect_fmax compares them as integers too, pow34.c:156-186)
+    for (int c = 0; c < 2; c++) {
+        int nl = c ? nl1 : nl0;
+        for (int j = LANE; j < nl; j += 64) {
+            float v = pow34(L, L.xr[c][j]);
+            L.x34[c][j] = v;
+            atomicMax(reinterpret_cast<int *>(&L.x34max[c][L.band_of_line[j]]), __float_as_int(v));
+        }
     }
     SYNC();
-    const int ch = LANE >> 5, i = LANE & 31;
     if (i < (ch ? nb1 : nb0)) {
-        const float *y = &L.x34[ch][L.startBand[i]];
-        float m = 0.0f;
-        for (int j = 0; j < L.nBand[i]; j++) if (y[j] > m) m = y[j];
-        L.x34max[ch][i] = m;
+        const float m = L.x34max[ch][i];
         int gz = max(0, hx_round((0.017716950f * hx_mblog(L.mblog, m) + (104.585000f - 100.0f + 8.0f))));
         L.gzero[ch][i] = gz;
         L.gmin[ch][i] = max(0, gz - GMIN_OFFSET);
@@ -267,29 +367,30 @@ __device__ void startup_ms(AllocLds &L, const HxParams *p)
     SYNC();
     const int mnr = L.MNR;
     const int nl = p->hf_flag ? L.startBand[22] : p->nbmax[0];     // lines that get the M/S butterfly
+    // one pass over the lines: L/R energy terms, M/S butterfly (reference l3math.c:905-930, no
+    // 1/sqrt(2)), M/S energy terms (kept in the x34 array, which is not live yet)
     for (int j = LANE; j < nl; j += 64) {
         float l = L.xr[0][j], r = L.xr[1][j];
         L.term[0][j] = l * l;
         L.term[1][j] = r * r;
-    }
-    SYNC();
-    const int ch = LANE >> 5, i = LANE & 31;
-    const bool band = i < p->nsf[0];
-    if (band) L.xsxx[ch][i] = band_sum(&L.term[ch][L.startBand[i]], L.nBand[i], 0.0f);
-    SYNC();
-    for (int j = LANE; j < nl; j += 64) {       // reference l3math.c:905-930, no 1/sqrt(2)
-        float l = L.xr[0][j], r = L.xr[1][j];
         float x0 = (l + r), x1 = (l - r);
         unsigned char s0 = 0, s1 = 0;
         if (x0 < 0.0f) { s0 = 1; x0 = -x0; }
         if (x1 < 0.0f) { s1 = 1; x1 = -x1; }
         L.signx[0][j] = s0; L.signx[1][j] = s1;
         L.xr[0][j] = x0; L.xr[1][j] = x1;
-        L.term[0][j] = x0 * x0;
-        L.term[1][j] = x1 * x1;
+        L.x34[0][j] = x0 * x0;
+        L.x34[1][j] = x1 * x1;
     }
     SYNC();
-    if (band) L.xsxxms[ch][i] = band_sum(&L.term[ch][L.startBand[i]], L.nBand[i], 0.0f);
+    const int ch = LANE >> 5, i = LANE & 31;
+    const bool band = i < p->nsf[0];
+    if (band) {
+        float e0, e1;
+        band_sum2(&L.term[ch][L.startBand[i]], &L.x34[ch][L.startBand[i]], L.nBand[i], &e0, &e1);
+        L.xsxx[ch][i] = e0;
+        L.xsxxms[ch][i] = e1;
+    }
     SYNC();
     int act = 0;
     if (band) {     // lane (ch, i): left (ch 0) / right (ch 1) noise target
@@ -384,18 +485,8 @@ __device__ void seek_actual(AllocLds &L, const HxParams *p)
 // Band-parallel: channel ch lives in lanes 32*ch .. 32*ch+21; maxima / ORs are half-wave
 // reductions.  The M/S variant carries the running maximum from a silent channel 0 into
 // channel 1 (the reference only resets it on the non-silent path).
-__device__ __forceinline__ int half_max(int v)
-{
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int half_or(int v)
-{
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ int half_max(int v) { return hx_half_max(v); }
+__device__ __forceinline__ int half_or(int v) { return hx_half_or(v); }
 
 __device__ int scale_factors(AllocLds &L, const HxParams *p, int ms)
 {
@@ -412,9 +503,9 @@ __device__ int scale_factors(AllocLds &L, const HxParams *p, int ms)
     int g0init, g1init;
     if (ms) {
         g0init = L.hf_quant ? L.gsf_hf : -1;
-        int G0 = max(g0init, __shfl(gact, 0, 64));
+        int G0 = max(g0init, __builtin_amdgcn_readlane(gact, 0));
         // channel 0 silent -> its Gtmp (max of gzero, and of the initial value) leaks into channel 1
-        int leak = max(G0, __shfl(gzmax, 0, 64));
+        int leak = max(G0, __builtin_amdgcn_readlane(gzmax, 0));
         g1init = (G0 < 0) ? leak : -1;
     } else {
         g0init = L.gsf_hf_stereo[0];
@@ -490,8 +581,14 @@ __device__ int scale_factors(AllocLds &L, const HxParams *p, int ms)
 // reference bitallo3.cpp:1348-1396
 __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
 {
+    // The candidates of a band (scalefactor s, s - sdelta, ... while G - s stays below gzero - 4)
+    // do not depend on each other's result, so up to K of them are measured per pass for all
+    // bands at once; the band lane then replays the reference's scan over the results in order.
     const int ch = LANE >> 5, i = LANE & 31;
     const int m = min(13, p->nsf[ch]);
+    const int nl = L.startBand[13];                         // lines of sfb 0..12
+    const int K = min(6, 1152 / (2 * nl));
+    float *tf = &L.term[0][0];                               // [K][2][nl]
     int mode = 0, s = 0, s0 = 0, g0 = 0, GG = 0, sdelta = 2, smin = 0, nt = 0;
     if (i < m && L.active[ch][i] && (L.gsf[ch][i] < (L.gzero[ch][i] - 5))) {
         sdelta = 2 * (1 + L.scale[ch]);
@@ -504,17 +601,69 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
         mode = 1;
         if (!(s >= s0) || (GG - s) >= g0) mode = 2;        // loop body never runs
     }
-    if (i < NB) L.geval[ch][i] = (mode == 1) ? GG - s : -1;
-    SYNC();
     while (__any(mode == 1)) {
-        noise_sweep(L, p, L.startBand[13], L.startBand[13], L.tmpn);
+        int nc = 0;                                         // valid candidates of this pass (a prefix)
+        if (mode == 1)
+            for (int c = 0; c < K; c++) { int sc = s - c * sdelta; if (sc >= s0 && (GG - sc) < g0) nc = c + 1; else break; }
+        if (i < NB) { L.geval[ch][i] = (mode == 1) ? GG - s : -1; L.tmpn[ch][i] = nc; }
+        SYNC();
+        // sfb 0..12 end at line 88 / 90 / 102 (48 / 44.1 / 32 kHz): two line slots per lane and
+        // channel.  The per-line operands stay in registers over the candidate loop, and the
+        // four slots of a candidate are independent LDS chains.
+        const int ncmax = hx_wave_max(nc);
+        float sx34[4], sxr[4]; int sg[4], snc[4], sj[4], ssd[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cc = q >> 1, j = LANE + 64 * (q & 1);
+            const bool ok = j < nl;
+            const int jc = ok ? j : 0;
+            const int b = L.band_of_line[jc];
+            sx34[q] = L.x34[cc][jc];
+            sxr[q] = L.xr[cc][jc];
+            sg[q] = L.geval[cc][b];
+            snc[q] = (ok && sg[q] >= 0) ? L.tmpn[cc][b] : 0;
+            sg[q] = max(sg[q], 0);
+            ssd[q] = 2 * (1 + L.scale[cc]);
+            sj[q] = cc * nl + jc;
+        }
+        bool slow = false;
+        for (int c = 0; c < ncmax; c++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int g = min(sg[q] + c * ssd[q], 127);
+                bool fast;
+                const float v = noise_term(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q], &fast);
+                if (c < snc[q] && fast) tf[c * 2 * nl + sj[q]] = v;
+                slow |= (c < snc[q]) && !fast;
+            }
+        }
+        if (__any(slow)) {      // quantised values beyond the 256-entry table: rare
+            for (int c = 0; c < ncmax; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int g = min(sg[q] + c * ssd[q], 127);
+                    bool fast;
+                    noise_term(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q], &fast);
+                    if (c < snc[q] && !fast) tf[c * 2 * nl + sj[q]] = noise_term_slow(L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q]);
+                }
+        }
+        SYNC();
+        for (int u = LANE; u < ncmax * 26; u += 64) {
+            const int c = u / 26, r = u - 26 * c, cc = r / 13, b = r - 13 * cc;
+            if (L.geval[cc][b] >= 0 && c < L.tmpn[cc][b]) {
+                float sxx = band_sum(tf + c * 2 * nl + cc * nl + L.startBand[b], L.nBand[b], 0.0f);
+                L.lucky[c][cc][b] = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[b];
+            }
+        }
+        SYNC();
         if (mode == 1) {
-            int noise = L.tmpn[ch][i];
-            if (noise <= nt) { L.Noise[ch][i] = noise; smin = s; }
-            s -= sdelta;
+            for (int c = 0; c < nc; c++) {
+                const int noise = L.lucky[c][ch][i];
+                if (noise <= nt) { L.Noise[ch][i] = noise; smin = s - c * sdelta; }
+            }
+            s -= nc * sdelta;
             if (!(s >= s0) || (GG - s) >= g0) mode = 2;
         }
-        if (i < NB) L.geval[ch][i] = (mode == 1) ? GG - s : -1;
         SYNC();
     }
     if (mode == 2) {
@@ -552,32 +701,37 @@ __device__ void do_quant(AllocLds &L, const HxParams *p, int opt)
 // ---------------------------------------------------------------------------------------
 // Huffman region split, table choice and bit count for one channel
 // (reference bitalloc.cpp:310-420, 470-756; cnt.c:96-325).
-struct Cand { int n; int t[4]; int tmax; };
+// Candidate Huffman tables of a region by its largest value (reference cnttab.h:38-62,
+// bitalloc.cpp:310-420).  Scalars only: a runtime-indexed member array would live in scratch.
+struct Cand { int n, t0, t1, t2, t3, tmax; };
+
+__device__ __forceinline__ Cand mk_cand(int n, int t0, int t1, int t2, int t3, int tmax)
+{
+    Cand c; c.n = n; c.t0 = t0; c.t1 = t1; c.t2 = t2; c.t3 = t3; c.tmax = tmax;
+    return c;
+}
 
 __device__ __forceinline__ Cand candidates(int rmax)
 {
-    Cand c;
-    c.t[0] = c.t[1] = c.t[2] = c.t[3] = 0;
-    if (rmax <= 0) { c.n = 0; c.tmax = 0; }
-    else if (rmax == 1) { c.n = 2; c.t[0] = 1; c.t[1] = 3; c.tmax = 1; }
-    else if (rmax == 2) { c.n = 2; c.t[0] = 2; c.t[1] = 3; c.tmax = 2; }
-    else if (rmax == 3) { c.n = 2; c.t[0] = 5; c.t[1] = 6; c.tmax = 3; }
-    else if (rmax <= 5) { c.n = 4; c.t[0] = 7; c.t[1] = 8; c.t[2] = 9; c.t[3] = 12; c.tmax = 5; }
-    else if (rmax <= 7) { c.n = 4; c.t[0] = 10; c.t[1] = 11; c.t[2] = 12; c.t[3] = 15; c.tmax = 7; }
-    else if (rmax <= 15) { c.n = 2; c.t[0] = 13; c.t[1] = 15; c.tmax = 15; }
-    else if (rmax == 16) { c.n = 2; c.t[0] = 16; c.t[1] = 24; c.tmax = 16; }
-    else if (rmax <= 18) { c.n = 2; c.t[0] = 17; c.t[1] = 24; c.tmax = 18; }
-    else if (rmax <= 22) { c.n = 2; c.t[0] = 18; c.t[1] = 24; c.tmax = 22; }
-    else if (rmax <= 30) { c.n = 2; c.t[0] = 19; c.t[1] = 24; c.tmax = 30; }
-    else if (rmax <= 46) { c.n = 2; c.t[0] = 25; c.t[1] = 20; c.tmax = 46; }
-    else if (rmax <= 78) { c.n = 2; c.t[0] = 20; c.t[1] = 26; c.tmax = 78; }
-    else if (rmax <= 142) { c.n = 2; c.t[0] = 27; c.t[1] = 21; c.tmax = 142; }
-    else if (rmax <= 270) { c.n = 2; c.t[0] = 21; c.t[1] = 28; c.tmax = 270; }
-    else if (rmax <= 526) { c.n = 2; c.t[0] = 29; c.t[1] = 22; c.tmax = 526; }
-    else if (rmax <= 1038) { c.n = 2; c.t[0] = 22; c.t[1] = 30; c.tmax = 1038; }
-    else if (rmax <= 2062) { c.n = 2; c.t[0] = 30; c.t[1] = 23; c.tmax = 2062; }
-    else { c.n = 2; c.t[0] = 31; c.t[1] = 23; c.tmax = 8206; }
-    return c;
+    if (rmax <= 0) return mk_cand(0, 0, 0, 0, 0, 0);
+    if (rmax == 1) return mk_cand(2, 1, 3, 0, 0, 1);
+    if (rmax == 2) return mk_cand(2, 2, 3, 0, 0, 2);
+    if (rmax == 3) return mk_cand(2, 5, 6, 0, 0, 3);
+    if (rmax <= 5) return mk_cand(4, 7, 8, 9, 12, 5);
+    if (rmax <= 7) return mk_cand(4, 10, 11, 12, 15, 7);
+    if (rmax <= 15) return mk_cand(2, 13, 15, 0, 0, 15);
+    if (rmax == 16) return mk_cand(2, 16, 24, 0, 0, 16);
+    if (rmax <= 18) return mk_cand(2, 17, 24, 0, 0, 18);
+    if (rmax <= 22) return mk_cand(2, 18, 24, 0, 0, 22);
+    if (rmax <= 30) return mk_cand(2, 19, 24, 0, 0, 30);
+    if (rmax <= 46) return mk_cand(2, 25, 20, 0, 0, 46);
+    if (rmax <= 78) return mk_cand(2, 20, 26, 0, 0, 78);
+    if (rmax <= 142) return mk_cand(2, 27, 21, 0, 0, 142);
+    if (rmax <= 270) return mk_cand(2, 21, 28, 0, 0, 270);
+    if (rmax <= 526) return mk_cand(2, 29, 22, 0, 0, 526);
+    if (rmax <= 1038) return mk_cand(2, 22, 30, 0, 0, 1038);
+    if (rmax <= 2062) return mk_cand(2, 30, 23, 0, 0, 2062);
+    return mk_cand(2, 31, 23, 0, 0, 8206);
 }
 
 // coded length of one pair in table t: Huffman length + sign bits + linbits
@@ -595,6 +749,30 @@ __device__ __forceinline__ int pair_len(const AllocLds &L, int t, int x, int y)
     return n + (x != 0) + (y != 0);
 }
 
+// packed 16-bit length sums of one pair for the candidates of a region
+__device__ __forceinline__ void acc_pair(const AllocLds &L, const Cand &c, int x, int y, int &p01, int &p23)
+{
+    if (c.n == 0) return;
+    p01 += pair_len(L, c.t0, x, y) | (pair_len(L, c.t1, x, y) << 16);
+    if (c.n == 4) p23 += pair_len(L, c.t2, x, y) | (pair_len(L, c.t3, x, y) << 16);
+}
+
+// pick the shortest candidate; ties go to the higher index (reference cnt.c:45,111-120)
+__device__ __forceinline__ int pick_table(const Cand &c, int p01, int p23, int live, int *bits)
+{
+    const int b0 = p01 & 0xFFFF, b1 = (p01 >> 16) & 0xFFFF, b2 = p23 & 0xFFFF, b3 = (p23 >> 16) & 0xFFFF;
+    int best = 0, t = c.t0;
+    if (c.n != 0 && live) {
+        if (b0 < b1) { best = b0; t = c.t0; } else { best = b1; t = c.t1; }
+        if (c.n == 4) {
+            if (b2 <= best) { best = b2; t = c.t2; }
+            if (b3 <= best) { best = b3; t = c.t3; }
+        }
+    }
+    *bits += best;
+    return t;
+}
+
 __device__ __forceinline__ int region_max(const int *ixmax, int a, int b)
 {
     int m = 0;
@@ -607,13 +785,14 @@ __device__ int count_bits_ch(AllocLds &L, const HxParams *p, int ch, int ncb)
     const int *ixmax = L.ixmax[ch];
     const int *ix = L.ix[ch];
     const int bt = L.block_type;
-    int cb0, cb1, cb2, cb3, i;
-    // region boundaries: cheap, computed redundantly by every lane (uniform)
-    for (i = ncb - 1; i >= 0; i--) if (ixmax[i] > 0) break;
-    cb3 = i + 1;
-    for (; i >= 0; i--) if (ixmax[i] > 1) break;
-    cb2 = i + 1;
+    int cb0, cb1, cb2, cb3;
+    // lane i holds ixmax[i]; the band scans of the reference become ballots
+    const int my = (LANE < ncb) ? ixmax[LANE] : 0;
+    const unsigned long long mk0 = __ballot(my > 0), mk1 = __ballot(my > 1);
+    cb3 = mk0 ? 64 - __clzll((long long) mk0) : 0;      // one past the last band with a non-zero line
+    cb2 = mk1 ? 64 - __clzll((long long) mk1) : 0;      // one past the last band with a value > 1
     cb0 = cb1 = 0;
+#define RMAX(a_, b_) hx_wave_max((LANE >= (a_) && LANE < (b_)) ? my : 0)
     if (bt == 0) { if (cb2 < 2) { cb2 = 2; if (cb3 < cb2) cb3 = cb2; } }
     else { cb0 = 8; cb2 = max(cb2, 8); cb3 = max(cb3, cb2); cb1 = cb0; }
     // topmost line > 1 in the last "big" band, topmost line > 0 in the last count1 band
@@ -638,34 +817,37 @@ __device__ int count_bits_ch(AllocLds &L, const HxParams *p, int ch, int ncb)
         if (cb0 < 1) cb0 = 1;
         if (cb1 <= cb0) cb1 = cb0 + 1;
         if (cb1 > cb0 + 8) cb1 = cb0 + 8;
-        c0 = candidates(region_max(ixmax, 0, cb0));
-        c1 = candidates(region_max(ixmax, cb0, cb1));
-        c2 = candidates(region_max(ixmax, cb1, cb2));
-        if (c2.tmax < c1.tmax) {
-            int j;
-            for (j = cb1 - 1; j > cb0; j--) if (ixmax[j] > c2.tmax) break;
+        c0 = candidates(RMAX(0, cb0));
+        c1 = candidates(RMAX(cb0, cb1));
+        c2 = candidates(RMAX(cb1, cb2));
+        if (c2.tmax < c1.tmax) {        // shrink region 1: last band in (cb0, cb1) above region 2's table range
+            const unsigned long long m = __ballot(my > c2.tmax && LANE > cb0 && LANE <= cb1 - 1);
+            const int j = m ? 63 - __clzll((long long) m) : cb0;
             cb1 = j + 1;
         }
-        if (c1.tmax < c0.tmax) {
-            int n = cb1 - 8, j;
+        if (c1.tmax < c0.tmax) {        // shrink region 0 (region 1 stays <= 8 bands)
+            int n = cb1 - 8;
             if (n < 1) n = 1;
-            for (j = cb0 - 1; j > n; j--) if (ixmax[j] > c1.tmax) break;
-            cb0 = j + 1;
+            if (cb0 - 1 > n) {
+                const unsigned long long m = __ballot(my > c1.tmax && LANE > n && LANE <= cb0 - 1);
+                const int j = m ? 63 - __clzll((long long) m) : n;
+                cb0 = j + 1;
+            }
         }
     } else {
-        c0 = candidates(region_max(ixmax, 0, cb0));
+        c0 = candidates(RMAX(0, cb0));
         c1 = candidates(0);
-        c2 = candidates(region_max(ixmax, cb0, cb2));
+        c2 = candidates(RMAX(cb0, cb2));
     }
+#undef RMAX
     const int n0 = L.startBand[cb0], n1 = L.startBand[cb1];
     // pair lengths: region 0 = [0,n0), region 1 = [n0,n1), region 2 = [n1,nbig)
-    int b[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    const int end = (nbig > n1) ? nbig : n1;      // region 1 is counted to n1 even beyond nbig
-    for (int j = 2 * LANE; j < end; j += 128) {
-        int x = ix[j], y = ix[j + 1];
-        if (j < n0) { for (int k = 0; k < c0.n; k++) b[0][k] += pair_len(L, c0.t[k], x, y); }
-        else if (j < n1) { if (bt == 0) for (int k = 0; k < c1.n; k++) b[1][k] += pair_len(L, c1.t[k], x, y); }
-        else { for (int k = 0; k < c2.n; k++) b[2][k] += pair_len(L, c2.t[k], x, y); }
+    int r0a = 0, r0b = 0, r1a = 0, r1b = 0, r2a = 0, r2b = 0;
+    for (int j = 2 * LANE; j < nbig; j += 128) {
+        const int x = ix[j], y = ix[j + 1];
+        if (j < n0) acc_pair(L, c0, x, y, r0a, r0b);
+        else if (j < n1) { if (bt == 0) acc_pair(L, c1, x, y, r1a, r1b); }
+        else acc_pair(L, c2, x, y, r2a, r2b);
     }
     int qa = 0, qb = 0;
     for (int q = LANE; q < nquads; q += 64) {
@@ -674,32 +856,24 @@ __device__ int count_bits_ch(AllocLds &L, const HxParams *p, int ch, int ncb)
         qa += L.quada_len[((v[0] << 3) + (v[1] << 2) + (v[2] << 1) + v[3]) & 15] + pop;
         qb += 4 + pop;
     }
-    int bits = 0, tab[4];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const Cand &c = (r == 0) ? c0 : (r == 1 ? c1 : c2);
-        int b0 = hx_wave_sum(b[r][0]) & 0xFFFF, b1 = hx_wave_sum(b[r][1]) & 0xFFFF;
-        int b2 = hx_wave_sum(b[r][2]) & 0xFFFF, b3 = hx_wave_sum(b[r][3]) & 0xFFFF;
-        int len = (r == 0) ? n0 : (r == 1 ? n1 - n0 : nbig - n1);
-        int best = 0, idx = 0;
-        if (c.n != 0 && len > 0 && !(r == 1 && bt != 0)) {
-            if (b0 < b1) { best = b0; idx = 0; } else { best = b1; idx = 1; }
-            if (c.n == 4) {
-                if (b2 <= best) { best = b2; idx = 2; }
-                if (b3 <= best) { best = b3; idx = 3; }
-            }
-        }
-        bits += best;
-        tab[r] = c.t[idx];
+    r0a = hx_wave_sum(r0a); r2a = hx_wave_sum(r2a);
+    if (c0.n == 4) r0b = hx_wave_sum(r0b);
+    if (c2.n == 4) r2b = hx_wave_sum(r2b);
+    if (bt == 0) { r1a = hx_wave_sum(r1a); if (c1.n == 4) r1b = hx_wave_sum(r1b); }
+    int bits = 0;
+    const int tab0 = pick_table(c0, r0a, r0b, n0 > 0, &bits);
+    int tab1 = pick_table(c1, r1a, r1b, (n1 - n0 > 0) && bt == 0, &bits);
+    const int tab2 = pick_table(c2, r2a, r2b, nbig - n1 > 0, &bits);
+    if (bt != 0) tab1 = tab2;
+    {
+        const int q = hx_wave_sum(qa | (qb << 16));
+        qa = q & 0xFFFF;
+        qb = (q >> 16) & 0xFFFF;
     }
-    if (bt != 0) tab[1] = tab[2];
-    qa = hx_wave_sum(qa);
-    qb = hx_wave_sum(qb);
     int qidx = 0;
     if (nquads > 0) { if (qa < qb) { bits += qa; qidx = 0; } else { bits += qb; qidx = 1; } }
-    tab[3] = qidx;
     if (LANE == 0) {
-        L.hs_table[ch][0] = tab[0]; L.hs_table[ch][1] = tab[1]; L.hs_table[ch][2] = tab[2]; L.hs_table[ch][3] = tab[3];
+        L.hs_table[ch][0] = tab0; L.hs_table[ch][1] = tab1; L.hs_table[ch][2] = tab2; L.hs_table[ch][3] = qidx;
         L.hs_cbreg[ch][0] = cb0; L.hs_cbreg[ch][1] = cb1; L.hs_cbreg[ch][2] = cb2;
         L.hs_nbig[ch] = nbig; L.hs_nquads[ch] = nquads; L.hs_bits[ch] = bits;
         L.huff_bits[ch] = bits;

@@ -29,7 +29,7 @@ __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long n
 struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
     const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
-    unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status;
+    unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status; unsigned long long *prof;
 };
 __global__ void k_alloc(AllocArgs a);
 
@@ -54,6 +54,7 @@ struct hx_batch {
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
     unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
     HxFrameDebug *d_dbg = nullptr;
+    unsigned long long *d_prof = nullptr;
     int lastNG = 0;                     // NG of the previous call (layout of the carry)
     bool debug = false;
     // staging for the host-buffer entry points
@@ -165,6 +166,8 @@ extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
         hipSetDevice(b->device);
         hipMalloc((void **) &b->d_dbg, sizeof(HxFrameDebug) * (size_t) b->S * b->maxF);
         hipMalloc((void **) &b->d_dbgmetric, sizeof(int) * (size_t) b->S * 2 * b->maxF * 2);
+        hipMalloc((void **) &b->d_prof, sizeof(unsigned long long) * (size_t) b->S * 32);
+        hipMemset(b->d_prof, 0, sizeof(unsigned long long) * (size_t) b->S * 32);
     }
 }
 
@@ -194,7 +197,7 @@ extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int
     AllocArgs a;
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
     a.msbase = b->d_msbase; a.bt = b->d_bt; a.btprev = b->d_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
-    a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status;
+    a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -281,6 +284,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "bt") { src = b->d_bt; n = S * NG; }
     else if (k == "eng") { src = b->d_eng; n = sizeof(int) * S * 2 * NG * 9; }
     else if (k == "dbg" && b->d_dbg) { src = b->d_dbg; n = sizeof(HxFrameDebug) * S * (NG / 2); }
+    else if (k == "prof" && b->d_prof) { src = b->d_prof; n = sizeof(unsigned long long) * S * 32; }
     else if (k == "state") { src = b->d_st; n = sizeof(HxStream) * S; }
     else if (k == "attack" && b->d_dbgmetric) { src = b->d_dbgmetric; n = sizeof(int) * S * NG * 2; }
     if (!src) return -1;

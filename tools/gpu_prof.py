@@ -1,0 +1,25 @@
+"""Phase profile of k_alloc (library must be built with HX_EXTRA=-DHX_PROFILE hmp3_amd/build.sh)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hmp3_amd import api, synth
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+kw = dict(bitrate=64, short_block_threshold=99999)
+pcm = synth.batch_pcm(S, F, unique=16)
+b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+b.debug_enable(True)
+b.encode_host(pcm)
+b.encode_host(pcm)
+prof = b.debug_read("prof", np.uint64, S * 32).reshape(S, 32).astype(np.float64)
+names = {0: "load xr", 1: "startup", 2: "seek_initial", 3: "seek_actual", 4: "trade_dual", 5: "scale_factors", 6: "big_lucky",
+         7: "do_quant", 8: "count_bits", 9: "increase_bits", 10: "decrease_bits", 11: "inverse_sf2", 12: "bitallo total",
+         13: "pack_huff", 14: "frame setup", 15: "compute_mask", 16: "pack_sf", 17: "flush+side", 18: "emit", 31: "kernel total"}
+tot = prof[:, 31].mean()
+print("mean cycles per frame (clock64 ticks), S=%d F=%d" % (S, F))
+for k in sorted(names):
+    v = prof[:, k].mean() / F
+    print("  %-16s %10.0f  %5.1f%%" % (names[k], v, 100 * prof[:, k].mean() / tot))
+print("  kernel ticks/frame %.0f" % (tot / F))
+ms, n = b.alloc_kernel_ms()
+print("k_alloc ms %.3f (%d calls)" % (ms, n))
