@@ -20,6 +20,21 @@
 #define PART23 4021
 #define NB 22
 
+// The scalar part of HxParams that the rate loop reads, staged in LDS: the class pointer comes
+// from a load, so every p->field on the global struct would be a vector memory round trip.
+// Field names match HxParams.
+struct AllocPrm {
+    unsigned char head[4];
+    int remainder, divisor, main_framebytes, sf_bit_max, AveTargetBits;
+    int ms_flag, hf_flag, vbr_flag;
+    int ivbr_min, ivbr_max, vbr_main_framebytes[16], vbr_pool_target;
+    int initialMNR, test1;
+    int nsf[2], nsf2[2], nsf3[2], nbmax[2], nbmax2[2], nbmax3[2];
+    float rnBand_l[22];
+    int nsfs, nbmax_s;
+    struct { int npart; } psyS;
+};
+
 struct alignas(16) AllocLds {
     float xr[2][576];
     float x34[2][576];
@@ -75,18 +90,22 @@ struct alignas(16) AllocLds {
     HxGr gr[2][2];
     int sfout[2][2][NB];
     int sfs[2][3][12];                  // short-block scalefactors of the current granule
+    AllocPrm P;
+    float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
 #ifdef HX_PROFILE
-    unsigned long long prof[32];
+    unsigned long long prof[64];
 #endif
 };
 
 #ifdef HX_PROFILE
 #define PROF(id, stmt) do { SYNC(); long long t0_ = clock64(); stmt; SYNC(); if (LANE == 0) L.prof[id] += (unsigned long long) (clock64() - t0_); } while (0)
 #define PROF_T0() long long tp_ = clock64()
+#define PROF_CNT(id) do { if (LANE == 0) L.prof[id] += 1; } while (0)
 #define PROF_ACC(id) do { SYNC(); if (LANE == 0) L.prof[id] += (unsigned long long) (clock64() - tp_); tp_ = clock64(); } while (0)
 #else
 #define PROF(id, stmt) do { stmt; } while (0)
 #define PROF_T0() do { } while (0)
+#define PROF_CNT(id) do { } while (0)
 #define PROF_ACC(id) do { } while (0)
 #endif
 #define LANE ((int) threadIdx.x)
@@ -120,15 +139,39 @@ __device__ __forceinline__ void put_bits64(AllocLds &L, int pos, unsigned long l
 // terms are fetched as 8-byte pairs, four pairs in flight, and added strictly in line order.
 __device__ __forceinline__ float band_sum(const float *t, int n, float acc)
 {
+    // Blocks of eight pairs, software pipelined (the next block's loads are in flight while the
+    // sixteen dependent adds of this one retire), then tails of 4 / 2 / 1 pairs.  Lanes with a
+    // narrower band simply drop out of the loops (exec mask), no per-element predicates.
     const float2 *t2 = reinterpret_cast<const float2 *>(t);
     const int m = n >> 1;
     int j = 0;
-    for (; j + 4 <= m; j += 4) {
+    if (m >= 8) {
+        float2 c[8], nx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = t2[k];
+        for (j = 8; j + 8 <= m; j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) nx[k] = t2[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { acc += c[k].x; acc += c[k].y; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = nx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc += c[k].x; acc += c[k].y; }
+    }
+    if (j + 4 <= m) {
         float2 a = t2[j], b = t2[j + 1], c = t2[j + 2], d = t2[j + 3];
         acc += a.x; acc += a.y; acc += b.x; acc += b.y;
         acc += c.x; acc += c.y; acc += d.x; acc += d.y;
+        j += 4;
     }
-    for (; j < m; j++) { float2 a = t2[j]; acc += a.x; acc += a.y; }
+    if (j + 2 <= m) {
+        float2 a = t2[j], b = t2[j + 1];
+        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
+        j += 2;
+    }
+    if (j < m) { float2 a = t2[j]; acc += a.x; acc += a.y; }
     return acc;
 }
 // two independent sums over the same band of two term arrays (same order each)
@@ -213,11 +256,27 @@ __device__ __noinline__ float noise_term_slow(float igain, float gain, float x34
     return tmp * tmp;
 }
 
-__device__ void noise_sweep(AllocLds &L, const HxParams *p, int nlines0, int nlines1, int out[2][NB])
+// Line operands of the gain search, held in registers for a whole seek_actual call: lane l owns
+// lines l, l+64, ... l+512 of both channels (x, x^(3/4), and the line's sfb).
+struct SweepRegs { float x34[2][9], xr[2][9]; int bnd[9]; };
+
+__device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R)
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int j = LANE + 64 * k;
+        R.bnd[k] = L.band_of_line[j];
+        R.x34[0][k] = L.x34[0][j]; R.x34[1][k] = L.x34[1][j];
+        R.xr[0][k] = L.xr[0][j]; R.xr[1][k] = L.xr[1][j];
+    }
+}
+
+__device__ __forceinline__ void noise_sweep(AllocLds &L, const SweepRegs &R, int nlines0, int nlines1, int out[2][NB])
 {
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
     // and the line range that any evaluated band touches
     int lo = 576, hi = 0;
+    PROF_T0();
     {
         const int bch = LANE >> 5, bi = LANE & 31;
         if (bi < NB) {
@@ -230,28 +289,38 @@ __device__ void noise_sweep(AllocLds &L, const HxParams *p, int nlines0, int nli
         hi = hx_wave_max(hi);
     }
     SYNC();
-    // Branch-free bodies, fully unrolled: the nine independent LDS chains of a lane overlap
-    // instead of paying the LDS latency nine times (one wave per SIMD has nothing else to run).
+    PROF_ACC(27);
+    // Branch-free bodies in chunks of three lines per lane (192 lines per chunk, chunks outside
+    // the evaluated range are skipped): per line one gain-pair read, one table read, one store.
+    // All loads of a chunk come before its stores: an LDS store in between would pin the later
+    // loads behind it (the compiler cannot tell the tables from the term buffer), and a
+    // predicated store would become a branch, so inactive lanes store into a sink.
+    bool slow = false;
+#pragma unroll
     for (int ch = 0; ch < 2; ch++) {
         const int nl = min(ch ? nlines1 : nlines0, hi);
-        if (lo >= nl) continue;
-        bool slow = false;
-        for (int j0 = lo + LANE; j0 - LANE < nl; j0 += 192) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int j = j0 + 64 * k;
-                const bool ok = j < nl;
-                const int jc = ok ? j : lo;
-                const int bnd = L.band_of_line[jc];
-                const float igain = L.gig[ch][bnd], gain = L.gg[ch][bnd];
+        for (int c3 = 0; c3 < 3; c3++) {
+            if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
+            float t[3];
+            float *dst[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int k = 3 * c3 + k3, j = LANE + 64 * k;
+                const float igain = L.gig[ch][R.bnd[k]], gain = L.gg[ch][R.bnd[k]];
                 bool fast;
-                const float t = noise_term(L, igain, gain, L.x34[ch][jc], L.xr[ch][jc], &fast);
-                const bool act = ok && igain >= 0.0f;
-                if (act && fast) L.term[ch][j] = t;
+                t[k3] = noise_term(L, igain, gain, R.x34[ch][k], R.xr[ch][k], &fast);
+                const bool act = j < nl && igain >= 0.0f;
+                dst[k3] = (act && fast) ? &L.term[ch][j] : &L.dump[LANE];
                 slow |= act && !fast;
             }
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) *dst[k3] = t[k3];
         }
-        if (__any(slow)) {      // values beyond the table: rare, recompute those lines with pow()
+    }
+    if (__any(slow)) {      // values beyond the table: rare, recompute those lines with pow()
+        for (int ch = 0; ch < 2; ch++) {
+            const int nl = min(ch ? nlines1 : nlines0, hi);
             for (int j = lo + LANE; j < nl; j += 64) {
                 const int bnd = L.band_of_line[j];
                 const float igain = L.gig[ch][bnd];
@@ -264,6 +333,7 @@ __device__ void noise_sweep(AllocLds &L, const HxParams *p, int nlines0, int nli
         }
     }
     SYNC();
+    PROF_ACC(28);
     {
         int ch = LANE >> 5, i = LANE & 31;
         if (i < NB && L.geval[ch][i] >= 0) {
@@ -272,11 +342,12 @@ __device__ void noise_sweep(AllocLds &L, const HxParams *p, int nlines0, int nli
         }
     }
     SYNC();
+    PROF_ACC(29);
 }
 
 // ---------------------------------------------------------------------------------------
 // reference bitallo3.cpp:1069-1126
-__device__ void adjust_nt(AllocLds &L, const HxParams *p)
+__device__ void adjust_nt(AllocLds &L, const AllocPrm *p)
 {
     const int f = p->test1;
     if (f == 0) return;
@@ -299,19 +370,36 @@ __device__ void adjust_nt(AllocLds &L, const HxParams *p)
 }
 
 // x^(3/4) of the first nl lines, band maxima, gzero / gmin (reference bitallo3.cpp:878-896)
-__device__ void pow34_gzero(AllocLds &L, const HxParams *p, int nl0, int nl1, int nb0, int nb1)
+__device__ void pow34_gzero(AllocLds &L, const AllocPrm *p, int nl0, int nl1, int nb0, int nb1)
 {
     const int ch = LANE >> 5, i = LANE & 31;
     if (i < NB) L.x34max[ch][i] = 0.0f;
     SYNC();
     // band maximum: x^(3/4) >= 0, so the float order equals the order of the bit patterns
     // (the reference's vect_fmax compares them as integers too, pow34.c:156-186)
+    // Chunks of three lines per lane, all loads (line, tables) ahead of the stores; lines past
+    // nl store into the per-lane sink so the chunk stays one basic block.
+#pragma unroll
     for (int c = 0; c < 2; c++) {
-        int nl = c ? nl1 : nl0;
-        for (int j = LANE; j < nl; j += 64) {
-            float v = pow34(L, L.xr[c][j]);
-            L.x34[c][j] = v;
-            atomicMax(reinterpret_cast<int *>(&L.x34max[c][L.band_of_line[j]]), __float_as_int(v));
+        const int nl = c ? nl1 : nl0;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) {
+            if (192 * c3 >= nl) continue;
+            float v[3];
+            int bnd[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int j = LANE + 64 * (3 * c3 + k3);
+                v[k3] = pow34(L, L.xr[c][j]);
+                bnd[k3] = L.band_of_line[j];
+            }
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int j = LANE + 64 * (3 * c3 + k3);
+                const bool ok = j < nl;
+                *(ok ? &L.x34[c][j] : &L.dump[LANE]) = v[k3];
+                atomicMax(reinterpret_cast<int *>(ok ? &L.x34max[c][bnd[k3]] : &L.dump[LANE]), __float_as_int(v[k3]));
+            }
         }
     }
     SYNC();
@@ -325,18 +413,32 @@ __device__ void pow34_gzero(AllocLds &L, const HxParams *p, int nl0, int nl1, in
 }
 
 // reference bitallo3.cpp:816-898
-__device__ void startup_lr(AllocLds &L, const HxParams *p)
+__device__ void startup_lr(AllocLds &L, const AllocPrm *p)
 {
     const int mnr = L.MNR + 100;
-    for (int ch = 0; ch < 2; ch++)
-        for (int j = LANE; j < p->nbmax3[ch]; j += 64) {
-            float x = L.xr[ch][j];
-            unsigned char sg = 0;
-            if (!(x >= 0.0f)) { sg = 1; x = -x; }
-            L.signx[ch][j] = sg;
-            L.xr[ch][j] = x;
-            L.term[ch][j] = x * x;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        const int nl = p->nbmax3[ch];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) {        // three lines per lane and chunk, loads first
+            if (192 * c3 >= nl) continue;
+            float x[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) x[k3] = L.xr[ch][LANE + 64 * (3 * c3 + k3)];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int j = LANE + 64 * (3 * c3 + k3);
+                if (j < nl) {
+                    float xa = x[k3];
+                    unsigned char sg = 0;
+                    if (!(xa >= 0.0f)) { sg = 1; xa = -xa; }
+                    L.signx[ch][j] = sg;
+                    L.xr[ch][j] = xa;
+                    L.term[ch][j] = xa * xa;
+                }
+            }
         }
+    }
     SYNC();
     const int ch = LANE >> 5, i = LANE & 31;
     int act = 0;
@@ -360,29 +462,42 @@ __device__ void startup_lr(AllocLds &L, const HxParams *p)
 }
 
 // reference bitallo3.cpp:902-1066
-__device__ void startup_ms(AllocLds &L, const HxParams *p)
+__device__ void startup_ms(AllocLds &L, const AllocPrm *p)
 {
     if (LANE == 0 && p->vbr_flag == 0 && L.call_count > 10 && (L.TargetBits - L.minTargetBits) < 100)
         L.MNR = min(L.MNR + 50, 2050);
     SYNC();
     const int mnr = L.MNR;
+    PROF_T0();
     const int nl = p->hf_flag ? L.startBand[22] : p->nbmax[0];     // lines that get the M/S butterfly
     // one pass over the lines: L/R energy terms, M/S butterfly (reference l3math.c:905-930, no
     // 1/sqrt(2)), M/S energy terms (kept in the x34 array, which is not live yet)
-    for (int j = LANE; j < nl; j += 64) {
-        float l = L.xr[0][j], r = L.xr[1][j];
-        L.term[0][j] = l * l;
-        L.term[1][j] = r * r;
-        float x0 = (l + r), x1 = (l - r);
-        unsigned char s0 = 0, s1 = 0;
-        if (x0 < 0.0f) { s0 = 1; x0 = -x0; }
-        if (x1 < 0.0f) { s1 = 1; x1 = -x1; }
-        L.signx[0][j] = s0; L.signx[1][j] = s1;
-        L.xr[0][j] = x0; L.xr[1][j] = x1;
-        L.x34[0][j] = x0 * x0;
-        L.x34[1][j] = x1 * x1;
+#pragma unroll
+    for (int c3 = 0; c3 < 3; c3++) {            // three lines per lane and chunk, loads first
+        if (192 * c3 >= nl) continue;
+        float lv[3], rv[3];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) { lv[k3] = L.xr[0][LANE + 64 * (3 * c3 + k3)]; rv[k3] = L.xr[1][LANE + 64 * (3 * c3 + k3)]; }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int j = LANE + 64 * (3 * c3 + k3);
+            if (j < nl) {
+                const float l = lv[k3], r = rv[k3];
+                L.term[0][j] = l * l;
+                L.term[1][j] = r * r;
+                float x0 = (l + r), x1 = (l - r);
+                unsigned char s0 = 0, s1 = 0;
+                if (x0 < 0.0f) { s0 = 1; x0 = -x0; }
+                if (x1 < 0.0f) { s1 = 1; x1 = -x1; }
+                L.signx[0][j] = s0; L.signx[1][j] = s1;
+                L.xr[0][j] = x0; L.xr[1][j] = x1;
+                L.x34[0][j] = x0 * x0;
+                L.x34[1][j] = x1 * x1;
+            }
+        }
     }
     SYNC();
+    PROF_ACC(32);
     const int ch = LANE >> 5, i = LANE & 31;
     const bool band = i < p->nsf[0];
     if (band) {
@@ -392,6 +507,7 @@ __device__ void startup_ms(AllocLds &L, const HxParams *p)
         L.xsxxms[ch][i] = e1;
     }
     SYNC();
+    PROF_ACC(33);
     int act = 0;
     if (band) {     // lane (ch, i): left (ch 0) / right (ch 1) noise target
         int cbw = L.logcbw[i];
@@ -418,11 +534,13 @@ __device__ void startup_ms(AllocLds &L, const HxParams *p)
         L.snr[1][b] = Ndiff - nt1;
     }
     SYNC();
+    PROF_ACC(34);
     pow34_gzero(L, p, p->nbmax2[0], p->nbmax2[1], p->nsf2[0], p->nsf2[1]);
+    PROF_ACC(35);
 }
 
 // reference bitallo3.cpp:1130-1160
-__device__ void seek_initial(AllocLds &L, const HxParams *p)
+__device__ void seek_initial(AllocLds &L, const AllocPrm *p)
 {
     const int ch = LANE >> 5, i = LANE & 31;
     if (i < p->nsf[ch]) {
@@ -442,7 +560,7 @@ __device__ void seek_initial(AllocLds &L, const HxParams *p)
 }
 
 // reference bitallo3.cpp:1164-1296: all bands walk their gain step concurrently
-__device__ void seek_actual(AllocLds &L, const HxParams *p)
+__device__ void seek_actual(AllocLds &L, const AllocPrm *p)
 {
     const int ch = LANE >> 5, i = LANE & 31;
     const bool band = i < p->nsf[ch];
@@ -455,9 +573,13 @@ __device__ void seek_actual(AllocLds &L, const HxParams *p)
         else { L.gsf[ch][i] = L.gzero[ch][i] + 5; L.Noise[ch][i] = L.Noise0[ch][i]; }
     }
     if (i < NB) L.geval[ch][i] = (mode == 1) ? s : -1;
+    SweepRegs R;
+    sweep_load(L, R);
+    const int nl0 = p->nbmax[0], nl1 = p->nbmax[1];
     SYNC();
     while (__any(mode != 0)) {
-        noise_sweep(L, p, p->nbmax[0], p->nbmax[1], L.tmpn);
+        PROF_CNT(20);
+        noise_sweep(L, R, nl0, nl1, L.tmpn);
         if (mode == 1) {
             int noise = L.tmpn[ch][i], dn = noise - NTarget;
             L.NTadjust[ch][i] = L.NTadjust[ch][i] + (dn >> 3);
@@ -488,7 +610,7 @@ __device__ void seek_actual(AllocLds &L, const HxParams *p)
 __device__ __forceinline__ int half_max(int v) { return hx_half_max(v); }
 __device__ __forceinline__ int half_or(int v) { return hx_half_or(v); }
 
-__device__ int scale_factors(AllocLds &L, const HxParams *p, int ms)
+__device__ int scale_factors(AllocLds &L, const AllocPrm *p, int ms)
 {
     const int ch = LANE >> 5, i = LANE & 31;
     const bool band = i < p->nsf[ch];
@@ -579,7 +701,7 @@ __device__ int scale_factors(AllocLds &L, const HxParams *p, int ms)
 }
 
 // reference bitallo3.cpp:1348-1396
-__device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
+__device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 {
     // The candidates of a band (scalefactor s, s - sdelta, ... while G - s stays below gzero - 4)
     // do not depend on each other's result, so up to K of them are measured per pass for all
@@ -602,6 +724,8 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
         if (!(s >= s0) || (GG - s) >= g0) mode = 2;        // loop body never runs
     }
     while (__any(mode == 1)) {
+        PROF_CNT(21);
+        PROF_T0();
         int nc = 0;                                         // valid candidates of this pass (a prefix)
         if (mode == 1)
             for (int c = 0; c < K; c++) { int sc = s - c * sdelta; if (sc >= s0 && (GG - sc) < g0) nc = c + 1; else break; }
@@ -611,6 +735,7 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
         // channel.  The per-line operands stay in registers over the candidate loop, and the
         // four slots of a candidate are independent LDS chains.
         const int ncmax = hx_wave_max(nc);
+        PROF_ACC(23);
         float sx34[4], sxr[4]; int sg[4], snc[4], sj[4], ssd[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -628,14 +753,18 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
         }
         bool slow = false;
         for (int c = 0; c < ncmax; c++) {
+            float v[4];
+            float *dst[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < 4; q++) {       // loads of the four chains ...
                 const int g = min(sg[q] + c * ssd[q], 127);
                 bool fast;
-                const float v = noise_term(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q], &fast);
-                if (c < snc[q] && fast) tf[c * 2 * nl + sj[q]] = v;
+                v[q] = noise_term(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q], &fast);
+                dst[q] = (c < snc[q] && fast) ? &tf[c * 2 * nl + sj[q]] : &L.dump[LANE];
                 slow |= (c < snc[q]) && !fast;
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++) *dst[q] = v[q];     // ... then the stores (see noise_sweep)
         }
         if (__any(slow)) {      // quantised values beyond the 256-entry table: rare
             for (int c = 0; c < ncmax; c++)
@@ -648,6 +777,7 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
                 }
         }
         SYNC();
+        PROF_ACC(24);
         for (int u = LANE; u < ncmax * 26; u += 64) {
             const int c = u / 26, r = u - 26 * c, cc = r / 13, b = r - 13 * cc;
             if (L.geval[cc][b] >= 0 && c < L.tmpn[cc][b]) {
@@ -656,6 +786,7 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
             }
         }
         SYNC();
+        PROF_ACC(25);
         if (mode == 1) {
             for (int c = 0; c < nc; c++) {
                 const int noise = L.lucky[c][ch][i];
@@ -665,6 +796,7 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
             if (!(s >= s0) || (GG - s) >= g0) mode = 2;
         }
         SYNC();
+        PROF_ACC(26);
     }
     if (mode == 2) {
         L.sf[ch][i] = smin;
@@ -674,27 +806,47 @@ __device__ void big_lucky_noise(AllocLds &L, const HxParams *p)
 }
 
 // reference bitallo3.cpp:1540-1585 with l3math.c:656-694: quantise every coded band
-__device__ void do_quant(AllocLds &L, const HxParams *p, int opt)
+__device__ void do_quant(AllocLds &L, const AllocPrm *p, int opt)
 {
     const int ch = LANE >> 5, i = LANE & 31;
-    if (i < p->nsf[ch]) L.ixmax[ch][i] = 0;
+    if (i < NB) {
+        L.ixmax[ch][i] = (i < p->nsf[ch]) ? 0 : L.ixmax[ch][i];
+        L.gig[ch][i] = L.look_34igain[L.gsf[ch][i] & 127];     // the band's 1/gain^(3/4), read per line below
+    }
     SYNC();
-    for (int c = 0; c < 2; c++)
-        for (int j = LANE; j < p->nbmax[c]; j += 64) {
-            int b = L.band_of_line[j];
-            float igain = L.look_34igain[L.gsf[c][b]];
-            int q;
-            if (opt) {
-                float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
-                int iq = (int) t;
-                if (iq > 31) iq = 31;
-                q = (int) (t - L.quant_off[iq]);
-            } else {
-                q = (int) (igain * L.x34[c][j] + (0.5f - 0.0946f));
+    // three lines per lane and chunk: band -> igain -> rounding offset are dependent LDS reads,
+    // the three chains overlap; stores (and the band maximum) come after all loads of the chunk
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int nl = p->nbmax[c];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) {
+            if (192 * c3 >= nl) continue;
+            int q[3], b[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int j = LANE + 64 * (3 * c3 + k3);
+                b[k3] = L.band_of_line[j];
+                const float igain = L.gig[c][b[k3]];
+                if (opt) {
+                    float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
+                    int iq = (int) t;
+                    if (iq > 31) iq = 31;
+                    q[k3] = (int) (t - L.quant_off[iq < 0 ? 0 : iq]);
+                } else {
+                    q[k3] = (int) (igain * L.x34[c][j] + (0.5f - 0.0946f));
+                }
             }
-            L.ix[c][j] = q;
-            if (q > 0) atomicMax(&L.ixmax[c][b], q);
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int j = LANE + 64 * (3 * c3 + k3);
+                if (j < nl) {
+                    L.ix[c][j] = q[k3];
+                    if (q[k3] > 0) atomicMax(&L.ixmax[c][b[k3]], q[k3]);
+                }
+            }
         }
+    }
     SYNC();
 }
 
@@ -780,7 +932,7 @@ __device__ __forceinline__ int region_max(const int *ixmax, int a, int b)
     return m;
 }
 
-__device__ int count_bits_ch(AllocLds &L, const HxParams *p, int ch, int ncb)
+__device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
 {
     const int *ixmax = L.ixmax[ch];
     const int *ix = L.ix[ch];
@@ -881,8 +1033,9 @@ __device__ int count_bits_ch(AllocLds &L, const HxParams *p, int ch, int ncb)
     return bits;
 }
 
-__device__ int count_bits(AllocLds &L, const HxParams *p, const int *ncb)
+__device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
 {
+    PROF_CNT(22);
     int bits = count_bits_ch(L, p, 0, ncb[0]);
     bits += count_bits_ch(L, p, 1, ncb[1]);
     SYNC();

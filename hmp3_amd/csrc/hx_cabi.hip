@@ -166,8 +166,8 @@ extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
         hipSetDevice(b->device);
         hipMalloc((void **) &b->d_dbg, sizeof(HxFrameDebug) * (size_t) b->S * b->maxF);
         hipMalloc((void **) &b->d_dbgmetric, sizeof(int) * (size_t) b->S * 2 * b->maxF * 2);
-        hipMalloc((void **) &b->d_prof, sizeof(unsigned long long) * (size_t) b->S * 32);
-        hipMemset(b->d_prof, 0, sizeof(unsigned long long) * (size_t) b->S * 32);
+        hipMalloc((void **) &b->d_prof, sizeof(unsigned long long) * (size_t) b->S * 64);
+        hipMemset(b->d_prof, 0, sizeof(unsigned long long) * (size_t) b->S * 64);
     }
 }
 
@@ -284,7 +284,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "bt") { src = b->d_bt; n = S * NG; }
     else if (k == "eng") { src = b->d_eng; n = sizeof(int) * S * 2 * NG * 9; }
     else if (k == "dbg" && b->d_dbg) { src = b->d_dbg; n = sizeof(HxFrameDebug) * S * (NG / 2); }
-    else if (k == "prof" && b->d_prof) { src = b->d_prof; n = sizeof(unsigned long long) * S * 32; }
+    else if (k == "prof" && b->d_prof) { src = b->d_prof; n = sizeof(unsigned long long) * S * 64; }
     else if (k == "state") { src = b->d_st; n = sizeof(HxStream) * S; }
     else if (k == "attack" && b->d_dbgmetric) { src = b->d_dbgmetric; n = sizeof(int) * S * NG * 2; }
     if (!src) return -1;
