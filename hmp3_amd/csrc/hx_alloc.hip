@@ -91,6 +91,8 @@ struct alignas(16) AllocLds {
     int sfout[2][2][NB];
     int sfs[2][3][12];                  // short-block scalefactors of the current granule
     AllocPrm P;
+    int tabpk[32];                      // per Huffman table: code offset | row stride << 12 | linbits << 20
+    unsigned long long candpk[19];      // candidate tables per class of a region's largest value
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
 #ifdef HX_PROFILE
     unsigned long long prof[64];
@@ -174,19 +176,44 @@ __device__ __forceinline__ float band_sum(const float *t, int n, float acc)
     if (j < m) { float2 a = t2[j]; acc += a.x; acc += a.y; }
     return acc;
 }
-// two independent sums over the same band of two term arrays (same order each)
+// two independent sums over the same band of two term arrays (same order each), pipelined like
+// band_sum; the two add chains interleave
 __device__ __forceinline__ void band_sum2(const float *t, const float *u, int n, float *s0, float *s1)
 {
     const float2 *t2 = reinterpret_cast<const float2 *>(t), *u2 = reinterpret_cast<const float2 *>(u);
     const int m = n >> 1;
     float a0 = 0.0f, a1 = 0.0f;
     int j = 0;
-    for (; j + 2 <= m; j += 2) {
-        float2 a = t2[j], b = t2[j + 1], c = u2[j], d = u2[j + 1];
-        a0 += a.x; a1 += c.x; a0 += a.y; a1 += c.y;
-        a0 += b.x; a1 += d.x; a0 += b.y; a1 += d.y;
+    if (m >= 8) {
+        float2 c[8], d[8], nc[8], nd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { c[k] = t2[k]; d[k] = u2[k]; }
+        for (j = 8; j + 8 <= m; j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { nc[k] = t2[j + k]; nd[k] = u2[j + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { c[k] = nc[k]; d[k] = nd[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
     }
-    for (; j < m; j++) { float2 a = t2[j], c = u2[j]; a0 += a.x; a1 += c.x; a0 += a.y; a1 += c.y; }
+    if (j + 4 <= m) {
+        float2 c[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c[k] = t2[j + k]; d[k] = u2[j + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
+        j += 4;
+    }
+    if (j + 2 <= m) {
+        float2 c0 = t2[j], c1 = t2[j + 1], d0 = u2[j], d1 = u2[j + 1];
+        a0 += c0.x; a1 += d0.x; a0 += c0.y; a1 += d0.y;
+        a0 += c1.x; a1 += d1.x; a0 += c1.y; a1 += d1.y;
+        j += 2;
+    }
+    if (j < m) { float2 c0 = t2[j], d0 = u2[j]; a0 += c0.x; a1 += d0.x; a0 += c0.y; a1 += d0.y; }
     *s0 = a0;
     *s1 = a1;
 }
@@ -256,6 +283,23 @@ __device__ __noinline__ float noise_term_slow(float igain, float gain, float x34
     return tmp * tmp;
 }
 
+// Table-only variant for the hot loops: the index is clamped into the table, and the caller has
+// established per band (from the band's largest x^(3/4), the index is monotone in it) that no
+// line needs the pow() path - or repairs the band's lines afterwards.
+__device__ __forceinline__ float noise_term_fast(const AllocLds &L, float igain, float gain, float x34, float x)
+{
+    float tmp = (igain * x34 + (0.0f - 0.0946f));
+    const unsigned qx = (unsigned) (int) (tmp + copysignf(0.5f, tmp));
+    const float xhat = gain * L.look_ix43[min(qx, 255u)];
+    tmp = x - xhat;
+    return tmp * tmp;
+}
+__device__ __forceinline__ bool noise_band_needs_pow(float igain, float x34max)
+{
+    const float tmp = (igain * x34max + (0.0f - 0.0946f));
+    return (int) (tmp + copysignf(0.5f, tmp)) >= 256;
+}
+
 // Line operands of the gain search, held in registers for a whole seek_actual call: lane l owns
 // lines l, l+64, ... l+512 of both channels (x, x^(3/4), and the line's sfb).
 struct SweepRegs { float x34[2][9], xr[2][9]; int bnd[9]; };
@@ -271,31 +315,33 @@ __device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R)
     }
 }
 
-__device__ __forceinline__ void noise_sweep(AllocLds &L, const SweepRegs &R, int nlines0, int nlines1, int out[2][NB])
+// Band lane (ch, sfb) passes the gain step g it wants measured (-1: none) and gets the band's
+// noise back in a register; sbeg / send are the lane's band limits, kept by the caller.
+__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int g, int sbeg, int send, int nlines0, int nlines1)
 {
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
     // and the line range that any evaluated band touches
     int lo = 576, hi = 0;
+    bool bslow = false;
     PROF_T0();
     {
         const int bch = LANE >> 5, bi = LANE & 31;
         if (bi < NB) {
-            const int g = L.geval[bch][bi];
-            L.gig[bch][bi] = (g >= 0) ? L.look_34igain[g] : -1.0f;
+            const float ig = (g >= 0) ? L.look_34igain[g] : -1.0f;
+            L.gig[bch][bi] = ig;
             L.gg[bch][bi] = (g >= 0) ? L.look_gain[g] : 0.0f;
-            if (g >= 0) { lo = L.startBand[bi]; hi = lo + L.nBand[bi]; }
+            if (g >= 0) { lo = sbeg; hi = send; bslow = noise_band_needs_pow(ig, L.x34max[bch][bi]); }
         }
         lo = -hx_wave_max(-lo);
         hi = hx_wave_max(hi);
     }
     SYNC();
     PROF_ACC(27);
-    // Branch-free bodies in chunks of three lines per lane (192 lines per chunk, chunks outside
-    // the evaluated range are skipped): per line one gain-pair read, one table read, one store.
-    // All loads of a chunk come before its stores: an LDS store in between would pin the later
-    // loads behind it (the compiler cannot tell the tables from the term buffer), and a
-    // predicated store would become a branch, so inactive lanes store into a sink.
-    bool slow = false;
+    // Chunks of three lines per lane (192 lines per chunk, chunks outside the evaluated range are
+    // skipped): per line one gain-pair read, one table read, one store.  All loads of a chunk
+    // come before its stores (an LDS store in between would pin the later loads behind it: the
+    // compiler cannot tell the tables from the term buffer).  Lines of bands that are not being
+    // evaluated get a meaningless term, which nobody reads - cheaper than predicating the store.
 #pragma unroll
     for (int ch = 0; ch < 2; ch++) {
         const int nl = min(ch ? nlines1 : nlines0, hi);
@@ -303,22 +349,16 @@ __device__ __forceinline__ void noise_sweep(AllocLds &L, const SweepRegs &R, int
         for (int c3 = 0; c3 < 3; c3++) {
             if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
             float t[3];
-            float *dst[3];
 #pragma unroll
             for (int k3 = 0; k3 < 3; k3++) {
-                const int k = 3 * c3 + k3, j = LANE + 64 * k;
-                const float igain = L.gig[ch][R.bnd[k]], gain = L.gg[ch][R.bnd[k]];
-                bool fast;
-                t[k3] = noise_term(L, igain, gain, R.x34[ch][k], R.xr[ch][k], &fast);
-                const bool act = j < nl && igain >= 0.0f;
-                dst[k3] = (act && fast) ? &L.term[ch][j] : &L.dump[LANE];
-                slow |= act && !fast;
+                const int k = 3 * c3 + k3;
+                t[k3] = noise_term_fast(L, L.gig[ch][R.bnd[k]], L.gg[ch][R.bnd[k]], R.x34[ch][k], R.xr[ch][k]);
             }
 #pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) *dst[k3] = t[k3];
+            for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
         }
     }
-    if (__any(slow)) {      // values beyond the table: rare, recompute those lines with pow()
+    if (__any(bslow)) {     // some band reaches beyond the table: rare, redo its lines with pow()
         for (int ch = 0; ch < 2; ch++) {
             const int nl = min(ch ? nlines1 : nlines0, hi);
             for (int j = lo + LANE; j < nl; j += 64) {
@@ -334,15 +374,14 @@ __device__ __forceinline__ void noise_sweep(AllocLds &L, const SweepRegs &R, int
     }
     SYNC();
     PROF_ACC(28);
-    {
-        int ch = LANE >> 5, i = LANE & 31;
-        if (i < NB && L.geval[ch][i] >= 0) {
-            float sxx = band_sum(&L.term[ch][L.startBand[i]], L.nBand[i], 0.0f);
-            out[ch][i] = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[i];
-        }
+    int noise = 0;
+    if (g >= 0) {
+        const float sxx = band_sum(&L.term[LANE >> 5][sbeg], send - sbeg, 0.0f);
+        noise = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[LANE & 31];
     }
     SYNC();
     PROF_ACC(29);
+    return noise;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -564,42 +603,46 @@ __device__ void seek_actual(AllocLds &L, const AllocPrm *p)
 {
     const int ch = LANE >> 5, i = LANE & 31;
     const bool band = i < p->nsf[ch];
-    // per-lane state machine: mode 0 = idle/done, 1 = first measurement, 2 = walking down, 3 = walking up
+    // per-lane state machine: mode 0 = idle/done, 1 = first measurement, 2 = walking down, 3 = walking up.
+    // The lane's band data (target, limits, estimator feedback, result) stays in registers over the
+    // sweeps and is written back once.
     int mode = 0, s = 0, t = 0, NTarget = 0, absmin = 0, tnmin = 0, smin = 0, iter = 0, niter = 0;
+    int ntadj = 0, sbeg = 0, send = 0;
     if (band) {
         NTarget = L.NT[ch][i];
         s = L.gsf[ch][i];
+        ntadj = L.NTadjust[ch][i];
+        sbeg = L.startBand[i];
+        send = sbeg + L.nBand[i];
         if (L.Noise0[ch][i] > NTarget) mode = 1;
-        else { L.gsf[ch][i] = L.gzero[ch][i] + 5; L.Noise[ch][i] = L.Noise0[ch][i]; }
+        else { smin = L.gzero[ch][i] + 5; tnmin = L.Noise0[ch][i]; }
     }
-    if (i < NB) L.geval[ch][i] = (mode == 1) ? s : -1;
     SweepRegs R;
     sweep_load(L, R);
     const int nl0 = p->nbmax[0], nl1 = p->nbmax[1];
     SYNC();
     while (__any(mode != 0)) {
         PROF_CNT(20);
-        noise_sweep(L, R, nl0, nl1, L.tmpn);
+        const int noise = noise_sweep(L, R, (mode == 0) ? -1 : (mode == 1 ? s : t), sbeg, send, nl0, nl1);
         if (mode == 1) {
-            int noise = L.tmpn[ch][i], dn = noise - NTarget;
-            L.NTadjust[ch][i] = L.NTadjust[ch][i] + (dn >> 3);
+            const int dn = noise - NTarget;
+            ntadj += (dn >> 3);
             absmin = abs(dn); tnmin = noise; smin = s; iter = 0;
             if (dn > 100) { t = s - 1; niter = min(t, 20); mode = (niter > 0) ? 2 : 0; }
             else if (dn < -100) { t = s + 1; niter = 20; mode = 3; }
             else mode = 0;
-            if (mode == 0) { L.gsf[ch][i] = smin; L.Noise[ch][i] = tnmin; }
         } else if (mode == 2 || mode == 3) {
-            int tn = L.tmpn[ch][i], ad = abs(tn - NTarget);
-            if (ad < absmin) { absmin = ad; tnmin = tn; smin = t; }
+            const int ad = abs(noise - NTarget);
+            if (ad < absmin) { absmin = ad; tnmin = noise; smin = t; }
             iter++;
-            bool stop = (mode == 2) ? (tn <= NTarget) : (tn >= NTarget);
+            const bool stop = (mode == 2) ? (noise <= NTarget) : (noise >= NTarget);
             if (stop || iter >= niter) mode = 0;
             else t += (mode == 2) ? -1 : 1;
-            if (mode == 0) { L.gsf[ch][i] = smin; L.Noise[ch][i] = tnmin; }
         }
-        if (i < NB) L.geval[ch][i] = (mode != 0) ? t : -1;
-        SYNC();
     }
+    if (band) { L.gsf[ch][i] = smin; L.Noise[ch][i] = tnmin; L.NTadjust[ch][i] = ntadj; }
+    if (i < NB) L.geval[ch][i] = -1;
+    SYNC();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -700,6 +743,47 @@ __device__ int scale_factors(AllocLds &L, const AllocPrm *p, int ms)
     return 0;
 }
 
+// Noise terms of up to K candidates for the lines of sfb 0..12 of both channels, flattened to
+// t = ch * nl + line (sfb 0..12 end at line 88 / 90 / 102 at 48 / 44.1 / 32 kHz, so NQ = 3 or 4
+// slots of 64 lanes).  A lane keeps the operands of its slots in registers over the candidates;
+// three candidates x NQ slots are independent LDS chains per block, all loads ahead of the
+// stores.  Terms of (candidate, band) pairs that are not being measured are computed and stored
+// too - nobody reads them, and it keeps the loop free of predicates.
+template <int NQ>
+__device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, float *tf)
+{
+    float sx34[NQ], sxr[NQ];
+    int sg[NQ], ssd[NQ], stride[NQ];
+    float *base[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int t = LANE + 64 * q;
+        const bool ok = t < 2 * nl;
+        const int cc = (ok && t >= nl) ? 1 : 0, j = ok ? t - (cc ? nl : 0) : 0;
+        sx34[q] = L.x34[cc][j];
+        sxr[q] = L.xr[cc][j];
+        sg[q] = max(L.geval[cc][L.band_of_line[j]], 0);
+        ssd[q] = 2 * (1 + L.scale[cc]);
+        base[q] = ok ? &tf[t] : &L.dump[LANE];
+        stride[q] = ok ? 2 * nl : 0;
+    }
+    for (int c0 = 0; c0 < ncmax; c0 += 3) {
+        float v[3][NQ];
+#pragma unroll
+        for (int cu = 0; cu < 3; cu++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int g = min(sg[q] + (c0 + cu) * ssd[q], 127);
+                v[cu][q] = noise_term_fast(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q]);
+            }
+#pragma unroll
+        for (int cu = 0; cu < 3; cu++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (c0 + cu < ncmax) base[q][(c0 + cu) * stride[q]] = v[cu][q];
+    }
+}
+
 // reference bitallo3.cpp:1348-1396
 __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 {
@@ -726,74 +810,60 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
     while (__any(mode == 1)) {
         PROF_CNT(21);
         PROF_T0();
-        int nc = 0;                                         // valid candidates of this pass (a prefix)
-        if (mode == 1)
-            for (int c = 0; c < K; c++) { int sc = s - c * sdelta; if (sc >= s0 && (GG - sc) < g0) nc = c + 1; else break; }
+        // valid candidates of this pass: the longest prefix c = 0.. with s - c*sdelta >= s0 and
+        // G - s + c*sdelta < g0 (sdelta is 2 or 4)
+        int nc = 0;
+        if (mode == 1) {
+            const int sh = 1 + L.scale[ch];
+            nc = min(K, min(((s - s0) >> sh) + 1, (g0 - GG + s + sdelta - 1) >> sh));
+        }
         if (i < NB) { L.geval[ch][i] = (mode == 1) ? GG - s : -1; L.tmpn[ch][i] = nc; }
+        // work list of the sums: one entry (c, ch, sfb) per candidate, compacted over the band lanes
+        int *list = &L.ix[0][0];                            // ix is not live before do_quant
+        const int incl = hx_wave_scan(nc), total = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+        for (int c = 0; c < 6; c++) if (c < nc) list[incl - nc + c] = (c << 8) | (ch << 7) | i;
         SYNC();
-        // sfb 0..12 end at line 88 / 90 / 102 (48 / 44.1 / 32 kHz): two line slots per lane and
-        // channel.  The per-line operands stay in registers over the candidate loop, and the
-        // four slots of a candidate are independent LDS chains.
         const int ncmax = hx_wave_max(nc);
+        const bool bslow = mode == 1 && noise_band_needs_pow(L.look_34igain[GG - s], L.x34max[ch][i]);
         PROF_ACC(23);
-        float sx34[4], sxr[4]; int sg[4], snc[4], sj[4], ssd[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int cc = q >> 1, j = LANE + 64 * (q & 1);
-            const bool ok = j < nl;
-            const int jc = ok ? j : 0;
-            const int b = L.band_of_line[jc];
-            sx34[q] = L.x34[cc][jc];
-            sxr[q] = L.xr[cc][jc];
-            sg[q] = L.geval[cc][b];
-            snc[q] = (ok && sg[q] >= 0) ? L.tmpn[cc][b] : 0;
-            sg[q] = max(sg[q], 0);
-            ssd[q] = 2 * (1 + L.scale[cc]);
-            sj[q] = cc * nl + jc;
-        }
-        bool slow = false;
-        for (int c = 0; c < ncmax; c++) {
-            float v[4];
-            float *dst[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {       // loads of the four chains ...
-                const int g = min(sg[q] + c * ssd[q], 127);
-                bool fast;
-                v[q] = noise_term(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q], &fast);
-                dst[q] = (c < snc[q] && fast) ? &tf[c * 2 * nl + sj[q]] : &L.dump[LANE];
-                slow |= (c < snc[q]) && !fast;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) *dst[q] = v[q];     // ... then the stores (see noise_sweep)
-        }
-        if (__any(slow)) {      // quantised values beyond the 256-entry table: rare
+        if (2 * nl <= 192) lucky_terms<3>(L, nl, ncmax, tf);
+        else lucky_terms<4>(L, nl, ncmax, tf);
+        if (__any(bslow)) {     // a band reaches beyond the 256-entry table: rare, redo with pow()
             for (int c = 0; c < ncmax; c++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int g = min(sg[q] + c * ssd[q], 127);
-                    bool fast;
-                    noise_term(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q], &fast);
-                    if (c < snc[q] && !fast) tf[c * 2 * nl + sj[q]] = noise_term_slow(L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q]);
+                for (int t = LANE; t < 2 * nl; t += 64) {
+                    const int cc = t >= nl, j = t - (cc ? nl : 0), b = L.band_of_line[j];
+                    if (L.geval[cc][b] >= 0 && c < L.tmpn[cc][b]) {
+                        const int g = min(L.geval[cc][b] + c * 2 * (1 + L.scale[cc]), 127);
+                        bool fast;
+                        noise_term(L, L.look_34igain[g], L.look_gain[g], L.x34[cc][j], L.xr[cc][j], &fast);
+                        if (!fast) tf[c * 2 * nl + t] = noise_term_slow(L.look_34igain[g], L.look_gain[g], L.x34[cc][j], L.xr[cc][j]);
+                    }
                 }
         }
         SYNC();
         PROF_ACC(24);
-        for (int u = LANE; u < ncmax * 26; u += 64) {
-            const int c = u / 26, r = u - 26 * c, cc = r / 13, b = r - 13 * cc;
-            if (L.geval[cc][b] >= 0 && c < L.tmpn[cc][b]) {
-                float sxx = band_sum(tf + c * 2 * nl + cc * nl + L.startBand[b], L.nBand[b], 0.0f);
-                L.lucky[c][cc][b] = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[b];
-            }
+        for (int u = LANE; u < total; u += 64) {
+            const int e = list[u], c = e >> 8, cc = (e >> 7) & 1, b = e & 31;
+            float sxx = band_sum(tf + c * 2 * nl + cc * nl + L.startBand[b], L.nBand[b], 0.0f);
+            L.lucky[c][cc][b] = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[b];
         }
         SYNC();
         PROF_ACC(25);
-        if (mode == 1) {
-            for (int c = 0; c < nc; c++) {
-                const int noise = L.lucky[c][ch][i];
-                if (noise <= nt) { L.Noise[ch][i] = noise; smin = s - c * sdelta; }
+        {   // replay the reference's scan: the last candidate that meets the target wins
+            int nz[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) nz[c] = L.lucky[c][ch][min(i, 12)];
+            int best = 0;
+            bool hit = false;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                if (c < nc && nz[c] <= nt) { best = nz[c]; smin = s - c * sdelta; hit = true; }
+            if (hit) L.Noise[ch][i] = best;
+            if (mode == 1) {
+                s -= nc * sdelta;
+                if (!(s >= s0) || (GG - s) >= g0) mode = 2;
             }
-            s -= nc * sdelta;
-            if (!(s >= s0) || (GG - s) >= g0) mode = 2;
         }
         SYNC();
         PROF_ACC(26);
@@ -863,7 +933,7 @@ __device__ __forceinline__ Cand mk_cand(int n, int t0, int t1, int t2, int t3, i
     return c;
 }
 
-__device__ __forceinline__ Cand candidates(int rmax)
+__device__ __forceinline__ Cand candidates_chain(int rmax)
 {
     if (rmax <= 0) return mk_cand(0, 0, 0, 0, 0, 0);
     if (rmax == 1) return mk_cand(2, 1, 3, 0, 0, 1);
@@ -886,6 +956,30 @@ __device__ __forceinline__ Cand candidates(int rmax)
     return mk_cand(2, 31, 23, 0, 0, 8206);
 }
 
+// The same through the per-class table staged in LDS (class = position of rmax among the
+// thresholds 0,1,2,3,5,7,15 and 15 + 2^k): a handful of scalar ops and one read instead of the
+// compare chain on every call.
+__device__ __forceinline__ int cand_class(int rmax)
+{
+    if (rmax <= 3) return max(rmax, 0);
+    if (rmax <= 15) return rmax <= 5 ? 4 : (rmax <= 7 ? 5 : 6);
+    return min(7 + (31 - __clz(rmax - 15)), 18);
+}
+__device__ __forceinline__ int cand_class_rep(int c)     // smallest rmax of class c
+{
+    return c <= 3 ? c : (c == 4 ? 4 : (c == 5 ? 6 : (c == 6 ? 8 : 15 + (1 << (c - 7)))));
+}
+__device__ __forceinline__ unsigned long long cand_pack(const Cand &c)
+{
+    return (unsigned long long) (c.n | (c.t0 << 3) | (c.t1 << 8) | (c.t2 << 13) | (c.t3 << 18)) | ((unsigned long long) c.tmax << 23);
+}
+__device__ __forceinline__ Cand candidates(const AllocLds &L, int rmax)
+{
+    const unsigned long long pk = L.candpk[cand_class(rmax)];
+    const unsigned lo = (unsigned) pk;
+    return mk_cand(lo & 7, (lo >> 3) & 31, (lo >> 8) & 31, (lo >> 13) & 31, (lo >> 18) & 31, (int) (pk >> 23));
+}
+
 // coded length of one pair in table t: Huffman length + sign bits + linbits
 __device__ __forceinline__ int pair_len(const AllocLds &L, int t, int x, int y)
 {
@@ -898,6 +992,18 @@ __device__ __forceinline__ int pair_len(const AllocLds &L, int t, int x, int y)
     } else {
         n = L.huff_len[L.huff_off[t] + x * L.huff_dim[t] + y];
     }
+    return n + (x != 0) + (y != 0);
+}
+
+// table parameters packed into one word: code-table offset | row stride << 12 | linbits << 20
+// (tables >= 16 are 16 x 16 with escapes above 14; the smaller ones have no escapes)
+__device__ __forceinline__ int tab_pack(const AllocLds &L, int t) { return L.tabpk[t]; }
+__device__ __forceinline__ int pair_len_p(const AllocLds &L, int pk, int x, int y)
+{
+    const int off = pk & 0xFFF, dim = (pk >> 12) & 0xFF, lin = pk >> 20;
+    const int cx = min(x, 15), cy = min(y, 15);
+    int n = L.huff_len[off + cx * dim + cy];
+    n += (x >= 15 ? lin : 0) + (y >= 15 ? lin : 0);
     return n + (x != 0) + (y != 0);
 }
 
@@ -937,6 +1043,7 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
     const int *ixmax = L.ixmax[ch];
     const int *ix = L.ix[ch];
     const int bt = L.block_type;
+    PROF_T0();
     int cb0, cb1, cb2, cb3;
     // lane i holds ixmax[i]; the band scans of the reference become ballots
     const int my = (LANE < ncb) ? ixmax[LANE] : 0;
@@ -948,12 +1055,14 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
     if (bt == 0) { if (cb2 < 2) { cb2 = 2; if (cb3 < cb2) cb3 = cb2; } }
     else { cb0 = 8; cb2 = max(cb2, 8); cb3 = max(cb3, cb2); cb1 = cb0; }
     // topmost line > 1 in the last "big" band, topmost line > 0 in the last count1 band
+    PROF_ACC(36);
     int lo2 = L.startBand[cb2 - 1], hi2 = L.startBand[cb2], lo3 = L.startBand[cb3 - 1], hi3 = L.startBand[cb3];
     int j2 = lo2, j3 = lo3;
     for (int j = lo2 + LANE; j < hi2; j += 64) if (ix[j] > 1) j2 = j;
     for (int j = lo3 + LANE; j < hi3; j += 64) if (ix[j] > 0) j3 = j;
     j2 = hx_wave_max(j2);
     j3 = hx_wave_max(j3);
+    PROF_ACC(37);
     int nbig = (j2 + 2) & (~1);
     if (bt == 0) { if (nbig < L.startBand[2]) nbig = L.startBand[2]; }
     else { if (nbig < L.startBand[8]) nbig = L.startBand[8]; }
@@ -969,9 +1078,9 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
         if (cb0 < 1) cb0 = 1;
         if (cb1 <= cb0) cb1 = cb0 + 1;
         if (cb1 > cb0 + 8) cb1 = cb0 + 8;
-        c0 = candidates(RMAX(0, cb0));
-        c1 = candidates(RMAX(cb0, cb1));
-        c2 = candidates(RMAX(cb1, cb2));
+        c0 = candidates(L, RMAX(0, cb0));
+        c1 = candidates(L, RMAX(cb0, cb1));
+        c2 = candidates(L, RMAX(cb1, cb2));
         if (c2.tmax < c1.tmax) {        // shrink region 1: last band in (cb0, cb1) above region 2's table range
             const unsigned long long m = __ballot(my > c2.tmax && LANE > cb0 && LANE <= cb1 - 1);
             const int j = m ? 63 - __clzll((long long) m) : cb0;
@@ -987,31 +1096,87 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
             }
         }
     } else {
-        c0 = candidates(RMAX(0, cb0));
-        c1 = candidates(0);
-        c2 = candidates(RMAX(cb0, cb2));
+        c0 = candidates(L, RMAX(0, cb0));
+        c1 = candidates(L, 0);
+        c2 = candidates(L, RMAX(cb0, cb2));
     }
 #undef RMAX
+    PROF_ACC(38);
     const int n0 = L.startBand[cb0], n1 = L.startBand[cb1];
-    // pair lengths: region 0 = [0,n0), region 1 = [n0,n1), region 2 = [n1,nbig)
+    // pair lengths: region 0 = [0,n0), region 1 = [n0,n1), region 2 = [n1,nbig).
+    // The table parameters of the three regions are wave-uniform and read once; a lane picks its
+    // region's parameters with selects, so a pair costs one table read per candidate and the
+    // five pairs of a lane are independent chains in one basic block.
     int r0a = 0, r0b = 0, r1a = 0, r1b = 0, r2a = 0, r2b = 0;
-    for (int j = 2 * LANE; j < nbig; j += 128) {
-        const int x = ix[j], y = ix[j + 1];
-        if (j < n0) acc_pair(L, c0, x, y, r0a, r0b);
-        else if (j < n1) { if (bt == 0) acc_pair(L, c1, x, y, r1a, r1b); }
-        else acc_pair(L, c2, x, y, r2a, r2b);
+    {
+        const int pa0 = tab_pack(L, c0.t0), pb0 = tab_pack(L, c0.t1);
+        const int pa1 = tab_pack(L, c1.t0), pb1 = tab_pack(L, c1.t1);
+        const int pa2 = tab_pack(L, c2.t0), pb2 = tab_pack(L, c2.t1);
+        const bool any4 = c0.n == 4 || c1.n == 4 || c2.n == 4;
+        int2 xy[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) xy[k] = reinterpret_cast<const int2 *>(ix)[min(LANE + 64 * k, 287)];
+        int acc[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int j = 2 * (LANE + 64 * k);
+            const int pa = (j < n0) ? pa0 : (j < n1 ? pa1 : pa2), pb = (j < n0) ? pb0 : (j < n1 ? pb1 : pb2);
+            acc[k] = pair_len_p(L, pa, xy[k].x, xy[k].y) | (pair_len_p(L, pb, xy[k].x, xy[k].y) << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int j = 2 * (LANE + 64 * k);
+            const int rn = (j < n0) ? c0.n : (j < n1 ? c1.n : c2.n);
+            const int v = (j < nbig && rn != 0) ? acc[k] : 0;
+            r0a += (j < n0) ? v : 0;
+            r1a += (j >= n0 && j < n1) ? v : 0;
+            r2a += (j >= n1) ? v : 0;
+        }
+        if (any4) {     // regions whose largest value is 4..7 have four candidate tables
+            const int qa0 = tab_pack(L, c0.t2), qb0 = tab_pack(L, c0.t3);
+            const int qa1 = tab_pack(L, c1.t2), qb1 = tab_pack(L, c1.t3);
+            const int qa2 = tab_pack(L, c2.t2), qb2 = tab_pack(L, c2.t3);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int j = 2 * (LANE + 64 * k);
+                const int pa = (j < n0) ? qa0 : (j < n1 ? qa1 : qa2), pb = (j < n0) ? qb0 : (j < n1 ? qb1 : qb2);
+                acc[k] = pair_len_p(L, pa, xy[k].x, xy[k].y) | (pair_len_p(L, pb, xy[k].x, xy[k].y) << 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int j = 2 * (LANE + 64 * k);
+                const int rn = (j < n0) ? c0.n : (j < n1 ? c1.n : c2.n);
+                const int v = (j < nbig && rn == 4) ? acc[k] : 0;
+                r0b += (j < n0) ? v : 0;
+                r1b += (j >= n0 && j < n1) ? v : 0;
+                r2b += (j >= n1) ? v : 0;
+            }
+        }
     }
+    PROF_ACC(39);
     int qa = 0, qb = 0;
-    for (int q = LANE; q < nquads; q += 64) {
-        const int *v = ix + nbig + 4 * q;
-        int pop = v[0] + v[1] + v[2] + v[3];
-        qa += L.quada_len[((v[0] << 3) + (v[1] << 2) + (v[2] << 1) + v[3]) & 15] + pop;
-        qb += 4 + pop;
+    {
+        int2 qv[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int q = min(LANE + 64 * k, max(nquads - 1, 0));
+            const int2 *v2 = reinterpret_cast<const int2 *>(ix + nbig + 4 * q);
+            qv[k][0] = v2[0]; qv[k][1] = v2[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int v0 = qv[k][0].x, v1 = qv[k][0].y, v2 = qv[k][1].x, v3 = qv[k][1].y;
+            const int pop = v0 + v1 + v2 + v3;
+            const int la = L.quada_len[((v0 << 3) + (v1 << 2) + (v2 << 1) + v3) & 15] + pop;
+            const bool ok = LANE + 64 * k < nquads;
+            qa += ok ? la : 0;
+            qb += ok ? 4 + pop : 0;
+        }
     }
+    PROF_ACC(40);
     r0a = hx_wave_sum(r0a); r2a = hx_wave_sum(r2a);
-    if (c0.n == 4) r0b = hx_wave_sum(r0b);
-    if (c2.n == 4) r2b = hx_wave_sum(r2b);
-    if (bt == 0) { r1a = hx_wave_sum(r1a); if (c1.n == 4) r1b = hx_wave_sum(r1b); }
+    r0b = hx_wave_sum(r0b); r2b = hx_wave_sum(r2b);     // unconditional: the DPP chains interleave
+    r1a = hx_wave_sum(r1a); r1b = hx_wave_sum(r1b);
     int bits = 0;
     const int tab0 = pick_table(c0, r0a, r0b, n0 > 0, &bits);
     int tab1 = pick_table(c1, r1a, r1b, (n1 - n0 > 0) && bt == 0, &bits);
@@ -1030,6 +1195,7 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
         L.hs_nbig[ch] = nbig; L.hs_nquads[ch] = nquads; L.hs_bits[ch] = bits;
         L.huff_bits[ch] = bits;
     }
+    PROF_ACC(41);
     return bits;
 }
 
