@@ -19,12 +19,8 @@ __global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, 
 __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
                              int *dbg_metric, int NG, int total);
 __global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
-__global__ void k_mdct(const float *sb, const HxStream *st, const HxParams *prm, const unsigned char *bt,
-                       float *xr, int NG, int SG, long long units);
-__global__ void k_psy(const float *xr, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
-                      float *etab, float *thr, const unsigned char *bt, int NG);
-__global__ void k_msmetric(const float *xr, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
-                           int *msbase, const unsigned char *bt, int NG);
+__global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
+                       float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
 __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S);
 struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
@@ -191,9 +187,8 @@ extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int
                        b->debug ? b->d_dbgmetric : nullptr, NG, tot);
     hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, b->d_bt, b->d_btprev, NG, S);
     long long units = (long long) S * NG * 2;
-    hipLaunchKernelGGL(k_mdct, dim3((unsigned) ((units + 1) / 2)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_bt, b->d_xr, NG, SG, units);
-    hipLaunchKernelGGL(k_psy, dim3((unsigned) units), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_etab, b->d_thr, b->d_bt, NG);
-    hipLaunchKernelGGL(k_msmetric, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_xr, b->d_st, b->d_prm, b->d_gt, b->d_msbase, b->d_bt, NG);
+    hipLaunchKernelGGL(k_spec, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_gt, b->d_bt, b->d_xr,
+                       b->d_etab, b->d_thr, b->d_msbase, NG, SG);
     AllocArgs a;
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
     a.msbase = b->d_msbase; a.bt = b->d_bt; a.btprev = b->d_btprev; a.out = d_out; a.out_bytes = d_out_bytes;

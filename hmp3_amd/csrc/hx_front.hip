@@ -305,109 +305,25 @@ __device__ __forceinline__ void mdct6x3(const HxParams *p, const float *f, float
     }
 }
 
-// One lane = one subband of one (stream, channel, granule); 2 granule-channels per wave.
-// Frequency inversion (hwin.c:282) is applied while reading, so the stored subband samples
-// stay un-inverted; the alias butterflies exchange 8 values with each neighbour lane.
-__global__ __launch_bounds__(64) void k_mdct(const float *__restrict__ sb, const HxStream *__restrict__ st,
-                                             const HxParams *__restrict__ prm,
-                                             const unsigned char *__restrict__ bt,
-                                             float *__restrict__ xr, int NG, int SG, long long units)
-{
-    const int lane = threadIdx.x, sbnd = lane & 31;
-    long long u = (long long) blockIdx.x * 2 + (lane >> 5);   // unit = (s, g, ch)
-    bool live = u < units;
-    if (!live) u = units - 1;
-    const int ch = (int) (u & 1);
-    const long long sg = u >> 1;
-    const int g = (int) (sg % NG), s = (int) (sg / NG);
-    const HxParams *p = prm + st[s].cls;
-    const int nsb = p->nsb_ms0;
-    const int btype = bt[(long long) s * NG + g];
-    const float *x1 = sb + ((long long) (s * 2 + ch) * SG + g) * 576 + sbnd * 18;     // S[g-3]
-    const float *x2 = x1 + 576;                                                             // S[g-2]
-    float y[18], f[18];
-    const bool act = sbnd < nsb;
-    if (act) {
-        float p1[18], p2[18];
-        const bool inv = (sbnd & 1) != 0;       // odd subbands: negate odd time slots
-#pragma unroll
-        for (int i = 0; i < 18; i++) {
-            float a = x1[i], b = x2[i];
-            if (inv && (i & 1)) { a = -a; b = -b; }
-            p1[i] = a; p2[i] = b;
-        }
-        if (btype != 2) {
-            const float *w = p->win[btype];
-#pragma unroll
-            for (int j = 0; j < 9; j++) {
-                f[j] = w[26 - j] * p2[8 - j] + w[27 + j] * p2[9 + j];
-                f[9 + j] = w[j] * p1[j] + w[17 - j] * p1[17 - j];
-            }
-            mdct18(p, f, y);
-        } else {        // short: three overlapping 12-tap windows (reference hwin.c:228-278)
-            const float *w = p->win[2];
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                f[q] = w[8 - q] * p1[14 - q] + w[9 + q] * p1[15 + q];
-                f[3 + q] = w[q] * p1[6 + q] + w[5 - q] * p1[11 - q];
-                f[6 + q] = w[8 - q] * p2[2 - q] + w[9 + q] * p2[3 + q];
-                f[9 + q] = w[q] * p1[12 + q] + w[5 - q] * p1[17 - q];
-                f[12 + q] = w[8 - q] * p2[8 - q] + w[9 + q] * p2[9 + q];
-                f[15 + q] = w[q] * p2[q] + w[5 - q] * p2[5 - q];
-            }
-            mdct6x3(p, f, y);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 18; i++) y[i] = 0.0f;
-    }
-    // alias reduction between subband k (lane) and k+1: x[17-i] with next lane's x[i]
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        float up = __shfl_down(y[i], 1, 64);            // next subband's element i
-        float dn = __shfl_up(y[17 - i], 1, 64);         // previous subband's element 17-i
-        float cs = p->csa[0][i], ca = p->csa[1][i];
-        float a = y[17 - i], b = y[i];
-        float na = a, nb = b;
-        if (btype != 2) {                                   // no alias reduction on short blocks
-            if (sbnd < nsb - 1) na = a * cs + up * ca;      // upper edge of this band
-            else if (sbnd == nsb - 1) na = a * cs;          // last coded band: half butterfly
-            if (sbnd >= 1 && sbnd < nsb) nb = b * cs - dn * ca;     // lower edge (pairs with band-1)
-        }
-        y[17 - i] = na;
-        y[i] = nb;
-    }
-    if (live) {
-        if (btype != 2) {
-            float *o = xr + ((sg * 2 + ch) * 576) + sbnd * 18;
-#pragma unroll
-            for (int i = 0; i < 18; i++) o[i] = y[i];
-        } else {                                            // [3 windows][192], line = 6*sb + k
-            float *o = xr + ((sg * 2 + ch) * 576) + sbnd * 6;
-#pragma unroll
-            for (int w = 0; w < 3; w++)
-#pragma unroll
-                for (int k = 0; k < 6; k++) o[192 * w + k] = y[6 * w + k];
-        }
-    }
-}
+// ---------------------------------------------------------------------------------------
+// K4: hybrid MDCT + psychoacoustic model + M/S metric of one (stream, granule), one wavefront.
+// The two subband blocks the transform needs (both channels) are fetched with coalesced 16-byte
+// loads into LDS; the spectrum goes back to global memory the same way and stays in LDS for the
+// psy model (lane = partition, channel after channel) and the M/S metric (lane = sfb), which
+// therefore never re-read it from HBM.
+//
+// MDCT: lane = subband of channel lane >> 5.  Frequency inversion (hwin.c:282) is applied while
+// reading, so the stored subband samples stay un-inverted; the alias butterflies exchange 8
+// values with each neighbour lane.
 
-// Psychoacoustic model, long blocks: one wave per (stream, granule, channel); lane = partition.
-// Outputs etab (energy + absolute threshold) and thr = a * stab (threshold before pre-echo control).
-__global__ __launch_bounds__(64) void k_psy(const float *__restrict__ xr, const HxStream *__restrict__ st,
-                                            const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
-                                            float *__restrict__ etab_out, float *__restrict__ thr_out,
-                                            const unsigned char *__restrict__ bt, int NG)
+// Psychoacoustic model of one channel; x = the channel's 576 lines (LDS).  Outputs etab (energy +
+// absolute threshold) and thr = a * stab (threshold before pre-echo control); for a short granule
+// thr holds mask[12*w + sfb] and etab is zero.
+__device__ __forceinline__ void psy_unit(const float *x, const HxParams *p, const HxGlobalTabs *gt, float *etab_out,
+                                         float *thr_out, bool is_short, float *xtab, float (*es)[64])
 {
-    __shared__ float xtab[64];
-    __shared__ float es[3][64];
     const int lane = threadIdx.x;
-    const long long u = blockIdx.x;             // (s, g, ch)
-    const int s = (int) ((u >> 1) / NG);
-    const HxParams *p = prm + st[s].cls;
-    const HxPsyTab *pt = &p->psyL;
-    const float *x = xr + u * 576;
-    if (bt[u >> 1] == 2) {
+    if (is_short) {
         // short block (reference emap.c:61-93, spdsmr.c:64-107): per-window partition energies,
         // then mask[w][sfb] = spread(2 sfb partitions); pre-echo control happens in the allocator
         const HxPsyTab *ps = &p->psyS;
@@ -433,13 +349,14 @@ __global__ __launch_bounds__(64) void k_psy(const float *__restrict__ xr, const 
                 for (int w = 0; w < 3; w++) b[w] += ps->w[r + j] * es[w][q + j];
             m0 = a[0] + b[0]; m1 = a[1] + b[1]; m2 = a[2] + b[2];
         }
-        etab_out[u * 64 + lane] = 0.0f;
-        float v = 0.0f;
+        etab_out[lane] = 0.0f;
         // thr layout for short granules: [12*w + sfb]
-        if (lane < 12) { thr_out[u * 64 + lane] = m0; thr_out[u * 64 + 12 + lane] = m1; thr_out[u * 64 + 24 + lane] = m2; }
-        else if (lane >= 36) thr_out[u * 64 + lane] = v;
+        if (lane < 12) { thr_out[lane] = m0; thr_out[12 + lane] = m1; thr_out[24 + lane] = m2; }
+        else if (lane >= 36) thr_out[lane] = 0.0f;
+        __syncthreads();
         return;
     }
+    const HxPsyTab *pt = &p->psyL;
     const float *w = pt->w;
     const float alpha = 0.30f;
     const int npart = pt->npart, npart2 = (npart + 1) & (~1);
@@ -488,22 +405,19 @@ __global__ __launch_bounds__(64) void k_psy(const float *__restrict__ xr, const 
     int m = lane >> 1;
     int dm = max(dm0 * max(m - 13, 0), 0);
     float a = hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, d + dm);
-    etab_out[u * 64 + lane] = (lane < npart2) ? et : 0.0f;
-    thr_out[u * 64 + lane] = (lane < npart2) ? a * stab : 0.0f;
+    etab_out[lane] = (lane < npart2) ? et : 0.0f;
+    thr_out[lane] = (lane < npart2) ? a * stab : 0.0f;
+    __syncthreads();        // xtab is reused by the next channel
 }
 
-// M/S decision metric before hysteresis: lane = scalefactor band (reference bitallo3.cpp:695-742)
-__global__ __launch_bounds__(64) void k_msmetric(const float *__restrict__ xr, const HxStream *__restrict__ st,
-                                                 const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
-                                                 int *__restrict__ msbase, const unsigned char *__restrict__ bt, int NG)
+// M/S decision metric before hysteresis: lane = scalefactor band (reference bitallo3.cpp:695-742);
+// x0 / x1 = the two channels' lines (LDS)
+__device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, const HxParams *p, const HxGlobalTabs *gt,
+                                              int *out, bool is_short)
 {
     const int lane = threadIdx.x;
-    const long long sg = blockIdx.x;            // (s, g)
-    const int s = (int) (sg / NG);
-    const HxParams *p = prm + st[s].cls;
-    const float *x0 = xr + sg * 1152, *x1 = x0 + 576;
     int v = 0;
-    if (bt[sg] == 2) {      // short block (reference bitallos.cpp:377-416): lane = (window, sfb)
+    if (is_short) {         // short block (reference bitallos.cpp:377-416): lane = (window, sfb)
         const int w = lane >> 4, i = lane & 15;
         int d = 0;
         if (w < 3 && i < p->nsfs) {
@@ -519,7 +433,7 @@ __global__ __launch_bounds__(64) void k_msmetric(const float *__restrict__ xr, c
             if ((double) s1 > 0.95 * (double) s0) d += 2;
         }
         d = hx_wave_sum(d);
-        if (lane == 0) msbase[sg] = (p->nsfs - d) << 10;
+        if (lane == 0) *out = (p->nsfs - d) << 10;
         return;
     }
     if (lane < p->nsf[0]) {
@@ -542,7 +456,116 @@ __global__ __launch_bounds__(64) void k_msmetric(const float *__restrict__ xr, c
         v = n * (mblr - mbsd);
     }
     v = hx_wave_sum(v);
-    if (lane == 0) msbase[sg] = v;
+    if (lane == 0) *out = v;
+}
+
+__global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const HxStream *__restrict__ st,
+                                             const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
+                                             const unsigned char *__restrict__ bt,
+                                             float *__restrict__ xr, float *__restrict__ etab_out, float *__restrict__ thr_out,
+                                             int *__restrict__ msbase, int NG, int SG)
+{
+    // in: [ch][S[g-3] | S[g-2]][576] subband samples; the first 2 x 576 floats are reused as the
+    // spectrum [ch][576] once every lane holds its inputs in registers
+    __shared__ __attribute__((aligned(16))) float in[2][2][576];
+    __shared__ float xtab[64];
+    __shared__ float es[3][64];
+    const int lane = threadIdx.x, sbnd = lane & 31, ch = lane >> 5;
+    const long long sg = blockIdx.x;            // (s, g)
+    const int g = (int) (sg % NG), s = (int) (sg / NG);
+    const HxParams *p = prm + st[s].cls;
+    const int nsb = p->nsb_ms0;
+    const int btype = bt[sg];
+    {   // 2 x 1152 contiguous floats per channel, 16 bytes per lane and load
+        float4 v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int e = lane + 64 * k, c = e / 288, r = e - 288 * c;       // 288 float4 per channel
+            v[k] = reinterpret_cast<const float4 *>(sb + ((long long) (s * 2 + c) * SG + g) * 576)[r];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) reinterpret_cast<float4 *>(&in[0][0][0])[lane + 64 * k] = v[k];
+    }
+    __syncthreads();
+    const float *x1 = &in[ch][0][sbnd * 18];    // S[g-3]
+    const float *x2 = &in[ch][1][sbnd * 18];    // S[g-2]
+    float y[18], f[18];
+    const bool act = sbnd < nsb;
+    {
+        float p1[18], p2[18];
+        const bool inv = (sbnd & 1) != 0;       // odd subbands: negate odd time slots
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+            float a = x1[i], b = x2[i];
+            if (inv && (i & 1)) { a = -a; b = -b; }
+            p1[i] = a; p2[i] = b;
+        }
+        __syncthreads();                        // everyone has its inputs: `in` may be overwritten
+        if (!act) {
+#pragma unroll
+            for (int i = 0; i < 18; i++) y[i] = 0.0f;
+        } else if (btype != 2) {
+            const float *w = p->win[btype];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                f[j] = w[26 - j] * p2[8 - j] + w[27 + j] * p2[9 + j];
+                f[9 + j] = w[j] * p1[j] + w[17 - j] * p1[17 - j];
+            }
+            mdct18(p, f, y);
+        } else {        // short: three overlapping 12-tap windows (reference hwin.c:228-278)
+            const float *w = p->win[2];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                f[q] = w[8 - q] * p1[14 - q] + w[9 + q] * p1[15 + q];
+                f[3 + q] = w[q] * p1[6 + q] + w[5 - q] * p1[11 - q];
+                f[6 + q] = w[8 - q] * p2[2 - q] + w[9 + q] * p2[3 + q];
+                f[9 + q] = w[q] * p1[12 + q] + w[5 - q] * p1[17 - q];
+                f[12 + q] = w[8 - q] * p2[8 - q] + w[9 + q] * p2[9 + q];
+                f[15 + q] = w[q] * p2[q] + w[5 - q] * p2[5 - q];
+            }
+            mdct6x3(p, f, y);
+        }
+    }
+    // alias reduction between subband k (lane) and k+1: x[17-i] with next lane's x[i]
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float up = __shfl_down(y[i], 1, 64);            // next subband's element i
+        float dn = __shfl_up(y[17 - i], 1, 64);         // previous subband's element 17-i
+        float cs = p->csa[0][i], ca = p->csa[1][i];
+        float a = y[17 - i], b = y[i];
+        float na = a, nb = b;
+        if (btype != 2) {                                   // no alias reduction on short blocks
+            if (sbnd < nsb - 1) na = a * cs + up * ca;      // upper edge of this band
+            else if (sbnd == nsb - 1) na = a * cs;          // last coded band: half butterfly
+            if (sbnd >= 1 && sbnd < nsb) nb = b * cs - dn * ca;     // lower edge (pairs with band-1)
+        }
+        y[17 - i] = na;
+        y[i] = nb;
+    }
+    float *xl = &in[0][0][0];                   // spectrum [ch][576]
+    if (btype != 2) {
+        float *o = xl + ch * 576 + sbnd * 18;
+#pragma unroll
+        for (int i = 0; i < 18; i++) o[i] = y[i];
+    } else {                                    // [3 windows][192], line = 6*sb + k
+        float *o = xl + ch * 576 + sbnd * 6;
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) o[192 * w + k] = y[6 * w + k];
+    }
+    __syncthreads();
+    {   // spectrum to global memory, 16 bytes per lane and store
+        float4 *dst = reinterpret_cast<float4 *>(xr + sg * 1152);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = lane + 64 * k;
+            if (e < 288) dst[e] = reinterpret_cast<const float4 *>(xl)[e];
+        }
+    }
+    psy_unit(xl, p, gt, etab_out + sg * 128, thr_out + sg * 128, btype == 2, xtab, es);
+    psy_unit(xl + 576, p, gt, etab_out + sg * 128 + 64, thr_out + sg * 128 + 64, btype == 2, xtab, es);
+    msmetric_unit(xl, xl + 576, p, gt, msbase + sg, btype == 2);
 }
 
 // After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
