@@ -177,9 +177,9 @@ extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int
     const long long nsamp = 1152LL * nframes;
     // The subband carry sits in slots NG_prev..NG_prev+2 only if the previous call used another
     // frame count; k_carry always rolls it to slots 0..2, so nothing to do here.
-    dim3 g1(S * 2, (NG + K1_GPB - 1) / K1_GPB);
+    dim3 g1(S, (NG + K1_GPB - 1) / K1_GPB);
     const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
-    hipLaunchKernelGGL(k_polyphase, g1, dim3(256), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG);
+    hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG);
     int tot = S * 2 * NG * 9;
     hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot);
     tot = S * NG;

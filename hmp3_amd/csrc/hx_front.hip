@@ -50,48 +50,93 @@ __device__ __forceinline__ void dct_bfly(const float *x, float *f, const float *
 }
 
 // One lane = one time slot: 512-tap window folded to 32 values, then the 32-point DCT.
-__global__ __launch_bounds__(256) void k_polyphase(const int16_t *__restrict__ pcm, long long nsamp,
+// A workgroup stages the interleaved stereo PCM of K1_GPB granules (plus 480 samples of history)
+// for both channels with 16-byte loads that are all in flight before the first LDS store; waves
+// 0..3 then work on channel 0, waves 4..7 on channel 1.
+__global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ pcm, long long nsamp,
                                                    const HxStream *__restrict__ st,
                                                    const HxParams *__restrict__ prm,
                                                    const HxGlobalTabs *__restrict__ gt,
                                                    float *__restrict__ sb, int NG, int SG)
 {
-    __shared__ float xs[K1_LDS];
-    const int s = blockIdx.x >> 1, ch = blockIdx.x & 1;
+    __shared__ float xs2[2][K1_LDS];
+    __shared__ __attribute__((aligned(16))) float wr[512];
+    wr[threadIdx.x] = gt->anwin_r[threadIdx.x];
+    const int s = blockIdx.x, ch = threadIdx.x >> 8, lt = threadIdx.x & 255;
     const int g0 = blockIdx.y * K1_GPB;
     const int ng = min(K1_GPB, NG - g0);
     const int count = 480 + 576 * ng;
     const HxStream *ss = st + s;
     const HxParams *p = prm + ss->cls;
-    const int16_t *src = pcm + (long long) s * nsamp * 2 + ch;
-    for (int idx = threadIdx.x; idx < count; idx += 256) {
-        int n = 576 * g0 - 480 + idx;
-        float v = (n < 0) ? ss->pcm_hist[ch][480 + n] : (float) src[2 * (long long) n];
-        xs[idx + (idx >> 5)] = v;
+    const int16_t *src = pcm + (long long) s * nsamp * 2;       // interleaved L R
+    const long long n0 = 576LL * g0 - 480;                      // sample index of staged slot 0
+    const int hist = (g0 == 0) ? 480 : 0;                       // slots that come from the carry
+    if ((reinterpret_cast<unsigned long long>(pcm) & 15ull) == 0) {
+        const int nv = count >> 2, vh = hist >> 2;              // 4 stereo samples per 16 bytes
+        int4 w[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int v = threadIdx.x + 512 * r;
+            const int vc = min(max(v, vh), nv - 1);
+            w[r] = *reinterpret_cast<const int4 *>(src + 2 * (n0 + 4LL * vc));
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int v = threadIdx.x + 512 * r;
+            if (v >= vh && v < nv) {
+                const int q[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int idx = 4 * v + e, o = idx + (idx >> 5);
+                    xs2[0][o] = (float) (short) (q[e] & 0xFFFF);
+                    xs2[1][o] = (float) (short) (q[e] >> 16);
+                }
+            }
+        }
+    } else {
+        for (int idx = hist + threadIdx.x; idx < count; idx += 512) {
+            const long long n = n0 + idx;
+            xs2[0][idx + (idx >> 5)] = (float) src[2 * n];
+            xs2[1][idx + (idx >> 5)] = (float) src[2 * n + 1];
+        }
+    }
+    for (int idx = threadIdx.x; idx < 2 * hist; idx += 512) {
+        const int c = idx >= 480, i = idx - 480 * c;
+        xs2[c][i + (i >> 5)] = ss->pcm_hist[c][i];
     }
     __syncthreads();
-    const int gl = threadIdx.x / 18, t = threadIdx.x - gl * 18;
+    const float *xs = xs2[ch];
+    const int gl = lt / 18, t = lt - gl * 18;
     if (gl >= ng) return;
     const int base = 480 + 576 * gl + 32 * t + 31;          // newest sample of the slot
     const float *P = xs + (base + (base >> 5) - 526);       // P[526 - pad(off)] = sample of age off
-    const float *W = gt->anwin;
 #define XS(off) P[526 - ((off) + ((off) >> 5))]
+    // window taps from LDS in use order: four per 16-byte broadcast read
     float a[32], b[32];
     {
+        const float4 *w4 = reinterpret_cast<const float4 *>(wr);
         float s1 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) s1 += W[16 + 64 * j] * XS(16 + 64 * j);
+        for (int j = 0; j < 4; j++) {
+            const float4 w = w4[j];
+            s1 += w.x * XS(16 + 128 * j);
+            s1 += w.z * XS(16 + 128 * j + 64);
+        }
         b[0] = s1;
     }
 #pragma unroll
     for (int k = 1; k < 32; k++) {
         const int A = (k <= 16) ? 16 + k : 80 - k;
         const int B = (k <= 16) ? 16 - k : 16 + k;
+        const float4 *w4 = reinterpret_cast<const float4 *>(wr + 16 * k);
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            s1 += W[A + 64 * j] * XS(A + 64 * j);
-            s2 += W[B + 64 * j] * XS(B + 64 * j);
+        for (int j = 0; j < 4; j++) {
+            const float4 w = w4[j];
+            s1 += w.x * XS(A + 128 * j);
+            s2 += w.y * XS(B + 128 * j);
+            s1 += w.z * XS(A + 128 * j + 64);
+            s2 += w.w * XS(B + 128 * j + 64);
         }
         b[k] = s1 + s2;
     }

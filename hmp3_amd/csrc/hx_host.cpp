@@ -45,6 +45,11 @@ void hx_global_tabs(HxGlobalTabs *g)
         0.00185, 0.00177, 0.00170, 0.00163, 0.00157, 0.00152, 0.00146, 0.00141, 0.00136, 0.00132};
     memset(g, 0, sizeof(*g));
     for (int i = 0; i < 512; i++) g->anwin[i] = bits2f(HX_ANWIN_BITS[i]);
+    // K1 folds the 512 taps to 32 sums; output k adds taps A + 64 j and B + 64 j (j = 0..7)
+    for (int k = 0; k < 32; k++) {
+        const int A = (k == 0) ? 16 : ((k <= 16) ? 16 + k : 80 - k), B = (k == 0) ? 16 : ((k <= 16) ? 16 - k : 16 + k);
+        for (int j = 0; j < 8; j++) { g->anwin_r[16 * k + 2 * j] = g->anwin[A + 64 * j]; g->anwin_r[16 * k + 2 * j + 1] = g->anwin[B + 64 * j]; }
+    }
     for (int i = 0; i < 256; i++) {
         g->mblog[i] = (int) floor(1000.0 * log10(1.0 + (i + 0.5) / 256.0) + 0.5) - 38227;
         g->mbexp_lo[i] = (float) pow(10.0, i / 1000.0);

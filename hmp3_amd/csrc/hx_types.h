@@ -62,6 +62,7 @@ struct HxParams {
 // Class-independent tables.
 struct HxGlobalTabs {
     float anwin[512];
+    float anwin_r[512];                 // the same window in the order K1 uses it: [k][j][A tap, B tap]
     int mblog[256];
     float mbexp_lo[256], mbexp_hi[256];
     float pow34_exp[256], pow34_a[16], pow34_b[16];
