@@ -28,6 +28,21 @@ BYTES_IN_PER_FRAME = 1152 * 2 * 2          # int16 stereo
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(kernel, S, F):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs, gfx950 correction applied as MI355X_MICROARCH.md prescribes); None
+    when no pass exists for this workload.  Counters cannot be read from inside the timed run."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters_bench_1024x256.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d["workload"]["streams"] != S or d["workload"]["frames_per_step"] != F:
+            return None
+        return int(d["kernels"][kernel]["hbm_bytes_corrected"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def synth_batch_gpu(torch, nstreams, nframes, sr, dev, first_stream=0):
     """Same signal family as hmp3_amd/synth.py (tones with AM + high-passed random walk,
     R = 0.7 L + 0.3 R'), synthesised on the GPU; per-stream tone parameters from PCG64 with
@@ -182,6 +197,7 @@ def main():
         out_per_frame = out_total / float(S * F)
         alg_bytes = (BYTES_IN_PER_FRAME + out_per_frame) * S * F        # per launch of the dominant kernel
         ach = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        traffic = pmc_traffic("k_alloc", S, F)
         res = {
             "metric": "batched stereo 44.1kHz frames/sec (whole node), CBR-128",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,7 +209,7 @@ def main():
             "kernel_status": status,
             "bitstream_bytes_per_frame": round(out_per_frame, 2),
             "roofline": {"bound": "hbm", "kernel": "k_alloc", "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6) if ach else None, "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6) if ach else None, "traffic": traffic,
                          "kernel_ms": round(k_ms, 3), "launches": k_calls,
                          "algorithmic_bytes_per_frame": round(BYTES_IN_PER_FRAME + out_per_frame, 1)},
         }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     const int ng = min(K1_GPB, NG - g0);
     const int count = 480 + 576 * ng;
     const HxStream *ss = st + s;
-    const HxParams *p = prm + ss->cls;
+    const HxParams *p = prm + __builtin_amdgcn_readfirstlane(ss->cls);
     const int16_t *src = pcm + (long long) s * nsamp * 2;       // interleaved L R
     const long long n0 = 576LL * g0 - 480;                      // sample index of staged slot 0
     const int hist = (g0 == 0) ? 480 : 0;                       // slots that come from the carry
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
     const int lane = threadIdx.x, sbnd = lane & 31, ch = lane >> 5;
     const long long sg = blockIdx.x;            // (s, g)
     const int g = (int) (sg % NG), s = (int) (sg / NG);
-    const HxParams *p = prm + st[s].cls;
+    const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);      // wave-uniform: table reads become scalar loads
     const int nsb = p->nsb_ms0;
     const int btype = bt[sg];
     {   // 2 x 1152 contiguous floats per channel, 16 bytes per lane and load
