@@ -42,7 +42,7 @@ EXPORTS = [
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
-    "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_status",
+    "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host", "hx_batch_status",
     "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
 ]
 
@@ -95,6 +95,8 @@ def lib():
         L.hx_batch_out_stride.restype = C.c_longlong
         L.hx_batch_encode_s16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_encode_s16_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.hx_batch_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
         L.hx_batch_status.argtypes = [C.c_void_p]
         L.hx_batch_frames_bytes.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_frames_bytes.restype = IntPair
@@ -146,16 +148,18 @@ class Batch:
         return int(lib().hx_batch_out_stride(self.h, nframes))
 
     def encode_host(self, pcm):
-        """pcm: int16 [n, nframes*1152, 2] -> list of bytes per stream"""
-        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        """pcm: int16 (or float32 at int16 scale) [n, nframes*1152, 2] -> list of bytes per stream"""
+        f32 = np.asarray(pcm).dtype == np.float32
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32 if f32 else np.int16)
         assert pcm.shape[0] == self.n and pcm.shape[2] == 2 and pcm.shape[1] % 1152 == 0
         nfr = pcm.shape[1] // 1152
         stride = self.out_stride(nfr)
         out = np.zeros((self.n, stride), dtype=np.uint8)
         nb = np.zeros(self.n, dtype=np.int32)
-        r = lib().hx_batch_encode_s16_host(self.h, pcm.ctypes.data, nfr, out.ctypes.data, stride, nb.ctypes.data)
+        fn = lib().hx_batch_encode_f32_host if f32 else lib().hx_batch_encode_s16_host
+        r = fn(self.h, pcm.ctypes.data, nfr, out.ctypes.data, stride, nb.ctypes.data)
         if r != 0:
-            raise RuntimeError("hx_batch_encode_s16_host failed: " + last_error())
+            raise RuntimeError("hx_batch_encode host call failed: " + last_error())
         return [out[i, :nb[i]].tobytes() for i in range(self.n)]
 
     def encode_device(self, d_pcm_ptr, nframes, d_out_ptr, out_stride, d_out_bytes_ptr, stream=None):

@@ -14,14 +14,15 @@
 // kernels (hx_front.hip / hx_alloc.hip)
 #define K1_GPB 14
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
-                            const HxGlobalTabs *gt, float *sb, int NG, int SG);
+                            const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf);
+__global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S);
 __global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total);
 __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
                              int *dbg_metric, int NG, int total);
 __global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
 __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                        float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
-__global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S);
+__global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf);
 struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
     const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
@@ -47,6 +48,8 @@ struct hx_batch {
     HxGlobalTabs *d_gt = nullptr;
     HxStream *d_st = nullptr;
     float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
+    float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
+    bool any_dc = false;
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
     unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
     HxFrameDebug *d_dbg = nullptr;
@@ -78,7 +81,7 @@ extern "C" void hx_batch_destroy(hx_batch *b)
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
-                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes};
+                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &pr : b->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete b;
@@ -103,7 +106,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         if (k < 0) {
             HxParams p;
             if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: MPEG-1 stereo / joint stereo without intensity only)"); delete b; return nullptr; }
-            if (p.filter_dc) { set_err("filter_select=1 (DC blocker) is not on the GPU path yet"); delete b; return nullptr; }
+            if (p.filter_dc) b->any_dc = true;
             seen.push_back(*c);
             b->params.push_back(p);
             k = (int) seen.size() - 1;
@@ -132,6 +135,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_btprev, S);
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
+    if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 2304);
     HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(b->d_gt, &gt, sizeof(gt), hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(b->d_st, st.data(), sizeof(HxStream) * S, hipMemcpyHostToDevice));
@@ -167,8 +171,9 @@ extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
     }
 }
 
-extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
-                                          long long out_stride, int *d_out_bytes, void *stream)
+// one pass of the pipeline over the batch; the input is int16 (d_pcm) or fp32 at int16 scale (d_pcm32)
+static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, int nframes, unsigned char *d_out,
+                       long long out_stride, int *d_out_bytes, void *stream)
 {
     if (!b || nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range"); return -1; }
     hipStream_t q = (hipStream_t) stream;
@@ -179,7 +184,9 @@ extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int
     // frame count; k_carry always rolls it to slots 0..2, so nothing to do here.
     dim3 g1(S, (NG + K1_GPB - 1) / K1_GPB);
     const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
-    hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG);
+    const float *pcmf = b->any_dc ? b->d_pcmf : d_pcm32;       // fp32 samples the polyphase reads, or null for int16
+    if (b->any_dc) hipLaunchKernelGGL(k_dcfilter, dim3((2 * S + 63) / 64), dim3(64), 0, q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S);
+    hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf);
     int tot = S * 2 * NG * 9;
     hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot);
     tot = S * NG;
@@ -200,10 +207,22 @@ extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int
     hipLaunchKernelGGL(k_alloc, dim3(S), dim3(64), 0, q, a);
     HIPCHK(hipEventRecord(e1, q));
     b->pending.push_back({e0, e1});
-    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S);
+    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf);
     HIPCHK(hipGetLastError());
     b->lastNG = NG;
     return 0;
+}
+
+extern "C" int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
+                                          long long out_stride, int *d_out_bytes, void *stream)
+{
+    return encode_core(b, d_pcm, nullptr, nframes, d_out, out_stride, d_out_bytes, stream);
+}
+
+extern "C" int hx_batch_encode_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,
+                                          long long out_stride, int *d_out_bytes, void *stream)
+{
+    return encode_core(b, nullptr, d_pcm, nframes, d_out, out_stride, d_out_bytes, stream);
 }
 
 extern "C" float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls)
@@ -224,21 +243,33 @@ extern "C" float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls)
     return mean;
 }
 
-extern "C" int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out,
-                                        long long out_stride, int *out_bytes)
+static int encode_host(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
 {
     if (!b) return -1;
     HIPCHK(hipSetDevice(b->device));
-    long long pbytes = (long long) b->S * nframes * 1152 * 2 * sizeof(int16_t), obytes = (long long) b->S * out_stride;
+    long long pbytes = (long long) b->S * nframes * 1152 * 2 * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
     if (pbytes > b->pcm_cap) { if (b->d_pcm) hipFree(b->d_pcm); HIPCHK(hipMalloc((void **) &b->d_pcm, pbytes)); b->pcm_cap = pbytes; }
     if (obytes > b->out_cap) { if (b->d_out) hipFree(b->d_out); HIPCHK(hipMalloc((void **) &b->d_out, obytes)); b->out_cap = obytes; }
     HIPCHK(hipMemcpy(b->d_pcm, pcm, pbytes, hipMemcpyHostToDevice));
-    int r = hx_batch_encode_s16_device(b, b->d_pcm, nframes, b->d_out, out_stride, b->d_outbytes, nullptr);
+    int r = encode_core(b, is_f32 ? nullptr : (const int16_t *) b->d_pcm, is_f32 ? (const float *) b->d_pcm : nullptr, nframes,
+                        b->d_out, out_stride, b->d_outbytes, nullptr);
     if (r) return r;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_bytes, b->d_outbytes, sizeof(int) * b->S, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out, b->d_out, obytes, hipMemcpyDeviceToHost));
     return 0;
+}
+
+extern "C" int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out,
+                                        long long out_stride, int *out_bytes)
+{
+    return encode_host(b, pcm, 0, nframes, out, out_stride, out_bytes);
+}
+
+extern "C" int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
+                                        long long out_stride, int *out_bytes)
+{
+    return encode_host(b, pcm, 1, nframes, out, out_stride, out_bytes);
 }
 
 extern "C" int hx_batch_status(hx_batch *b)
@@ -364,12 +395,12 @@ extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
     return r;
 }
 
-static HX_IN_OUT encode_one(hx_enc *e, const int16_t *pcm, unsigned char *bs_out, int in_bytes)
+static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned char *bs_out, int in_bytes)
 {
     HX_IN_OUT x = {in_bytes, 0};
     int nb = 0;
     long long stride = (long long) e->outbuf.size();
-    if (hx_batch_encode_s16_host(e->b, pcm, 1, e->outbuf.data(), stride, &nb) == 0) {
+    if (encode_host(e->b, pcm, is_f32, 1, e->outbuf.data(), stride, &nb) == 0) {
         memcpy(bs_out, e->outbuf.data(), nb);
         x.out_bytes = nb;
         e->bytes += nb;
@@ -381,15 +412,8 @@ static HX_IN_OUT encode_one(hx_enc *e, const int16_t *pcm, unsigned char *bs_out
 
 extern "C" HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out)
 {
-    // the GPU path ingests 16-bit PCM; the float entry point takes float at int16 scale
-    // (pub/mp3enc.h:90-98), which is exact for integral values in range (the CLI's 16-bit case)
-    for (int i = 0; i < 2304; i++) {
-        float v = pcm[i];
-        if (v > 32767.0f) v = 32767.0f;
-        if (v < -32768.0f) v = -32768.0f;
-        e->pcm16[i] = (int16_t) v;
-    }
-    return encode_one(e, e->pcm16.data(), bs_out, 9216);
+    // float at int16 scale (pub/mp3enc.h:90-98), taken as is: the polyphase kernel reads fp32
+    return encode_one(e, pcm, 1, bs_out, 9216);
 }
 
 extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, int source_bits, int source_is_float,
@@ -408,7 +432,7 @@ extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, i
 
 extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out)
 {
-    if (e->src_bits == 16) return encode_one(e, (const int16_t *) pcm, bs_out, 4608);
+    if (e->src_bits == 16) return encode_one(e, pcm, 0, bs_out, 4608);
     if (e->src_bits == 32) {    // float in [-1, 1) is scaled by 32768 (srcc.cpp:805-808)
         std::vector<float> t(2304);
         const float *f = (const float *) pcm;

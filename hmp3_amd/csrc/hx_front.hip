@@ -57,7 +57,8 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
                                                    const HxStream *__restrict__ st,
                                                    const HxParams *__restrict__ prm,
                                                    const HxGlobalTabs *__restrict__ gt,
-                                                   float *__restrict__ sb, int NG, int SG)
+                                                   float *__restrict__ sb, int NG, int SG,
+                                                   const float *__restrict__ pcmf)
 {
     __shared__ float xs2[2][K1_LDS];
     __shared__ __attribute__((aligned(16))) float wr[512];
@@ -71,7 +72,14 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     const int16_t *src = pcm + (long long) s * nsamp * 2;       // interleaved L R
     const long long n0 = 576LL * g0 - 480;                      // sample index of staged slot 0
     const int hist = (g0 == 0) ? 480 : 0;                       // slots that come from the carry
-    if ((reinterpret_cast<unsigned long long>(pcm) & 15ull) == 0) {
+    if (pcmf) {             // DC-blocked input from k_dcfilter: fp32, interleaved like the PCM
+        const float2 *srcf = reinterpret_cast<const float2 *>(pcmf) + (long long) s * nsamp;
+        for (int idx = hist + threadIdx.x; idx < count; idx += 512) {
+            const float2 v = srcf[n0 + idx];
+            xs2[0][idx + (idx >> 5)] = v.x;
+            xs2[1][idx + (idx >> 5)] = v.y;
+        }
+    } else if ((reinterpret_cast<unsigned long long>(pcm) & 15ull) == 0) {
         const int nv = count >> 2, vh = hist >> 2;              // 4 stereo samples per 16 bytes
         int4 w[5];
 #pragma unroll
@@ -616,7 +624,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
 // After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
 // last 480 input samples into the stream state.
 __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const int16_t *__restrict__ pcm,
-                        long long nsamp, int NG, int SG, int S)
+                        long long nsamp, int NG, int SG, int S, const float *__restrict__ pcmf)
 {
     const int sc = blockIdx.x;                  // s*2 + ch
     const int s = sc >> 1, ch = sc & 1;
@@ -628,7 +636,42 @@ __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const
     for (int i = threadIdx.x; i < 480; i += blockDim.x) {
         long long n = nsamp - 480 + i;
         // fewer than 480 new samples never happens (a frame is 1152), so all come from this batch
-        ss->pcm_hist[ch][i] = (float) src[2 * n];
+        ss->pcm_hist[ch][i] = pcmf ? pcmf[((long long) s * nsamp + n) * 2 + ch] : (float) src[2 * n];
     }
     if (threadIdx.x == 0 && ch == 0) ss->frames_in += (int) (nsamp / 1152);
+}
+
+// K0 (only when some stream asked for it, E_CONTROL filter_select = 1): the input DC blocker
+// y = x - d, d += alpha * y (reference filter2.c:116-121,137-144).  A first-order recurrence
+// evaluated in the reference's order, so it is sequential per channel: one lane per
+// (stream, channel) walks its samples; streams without the filter are converted to float only.
+__global__ void k_dcfilter(const int16_t *__restrict__ pcm, const float *__restrict__ pcm32, long long nsamp,
+                           HxStream *__restrict__ st, const HxParams *__restrict__ prm, float *__restrict__ pcmf, int S)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * S) return;
+    const int s = u >> 1, ch = u & 1;
+    HxStream *ss = st + s;
+    const HxParams *p = prm + ss->cls;
+    const int16_t *src = pcm + (long long) s * nsamp * 2 + ch;
+    const float *srcf = pcm32 + (long long) s * nsamp * 2 + ch;
+    float *dst = pcmf + (long long) s * nsamp * 2 + ch;
+    if (!p->filter_dc) {
+        for (long long n = 0; n < nsamp; n++) dst[2 * n] = pcm32 ? srcf[2 * n] : (float) src[2 * n];
+        return;
+    }
+    const float alpha = p->filter_alpha;
+    float d = ss->dc[ch];
+    for (long long n0 = 0; n0 < nsamp; n0 += 8) {      // nsamp is a multiple of 1152
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = pcm32 ? srcf[2 * (n0 + k)] : (float) src[2 * (n0 + k)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float t = x[k] - d;
+            d = d + alpha * t;
+            dst[2 * (n0 + k)] = t;
+        }
+    }
+    ss->dc[ch] = d;
 }

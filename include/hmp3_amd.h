@@ -86,6 +86,12 @@ int hx_batch_encode_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, u
 /* same with host buffers (staged through the device, synchronous) */
 int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out,
                              long long out_stride, int *out_bytes);
+/* the same for fp32 PCM at int16 scale (+-32768), the form CMp3Enc::L3_audio_encode takes
+   (pub/mp3enc.h:90-98; a1 of the path: srcc.cpp:805-808 scales [-1,1) floats by 32768 first) */
+int hx_batch_encode_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,
+                               long long out_stride, int *d_out_bytes, void *stream);
+int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
+                             long long out_stride, int *out_bytes);
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
    there).  0 = healthy.  Synchronises. */
 int hx_batch_status(hx_batch *b);

@@ -138,6 +138,11 @@ class RefEncoder:
         n = self.r.ref_encode_s16(self.h, frame.ctypes.data, self.out)
         return bytes(self.out[:n])
 
+    def encode_f32(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.float32)
+        n = self.r.ref_encode(self.h, frame.ctypes.data, self.out)
+        return bytes(self.out[:n])
+
     def dump(self):
         d = RefDump()
         self.r.ref_dump(self.h, C.byref(d))

@@ -26,6 +26,7 @@ CONFIGS = {
     "vbr100_hf2_48k": dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000, short_block_threshold=99999),
     "cbr128_32k": dict(bitrate=64, samprate=32000, short_block_threshold=99999),
     "cbr128_48k": dict(bitrate=64, samprate=48000, short_block_threshold=99999),
+    "cbr128_dcfilter": dict(bitrate=64, filter_select=1, short_block_threshold=99999),    # -S1 (filter2.c:116-144)
     # block switching enabled (CLI default threshold 700); the signal carries noise bursts
     "cbr128_sw": dict(bitrate=64),
     "cbr128_lr_sw": dict(bitrate=64, mode=0),
@@ -71,6 +72,26 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
         assert (bt == 2).sum() > 0 and (bt == 1).sum() > 0 and (bt == 3).sum() > 0
     fb = [b.frames_bytes(s) for s in range(S)]
     assert all(f[1] == len(got[i]) for i, f in enumerate(fb))
+    b.close()
+
+
+def test_float_input_and_dc_filter_mixed_batch():
+    """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
+    streams with the DC blocker on"""
+    S, F = 6, 24
+    rng = np.random.default_rng(9)
+    pcm = np.stack([synth.stream_pcm(300 + i, F, rho=RHOS[i % 4]) for i in range(S)]).astype(np.float32)
+    pcm += rng.uniform(-0.49, 0.49, pcm.shape).astype(np.float32)
+    pcm[1] += 700.0         # a DC offset for the blocker to remove
+    kws = [dict(bitrate=64, short_block_threshold=99999, filter_select=(i & 1)) for i in range(S)]
+    b = api().Batch([api().default_control(**k) for k in kws], nstreams=S, max_frames=F)
+    got = b.encode_host(pcm[:, :12 * 1152])
+    got2 = b.encode_host(pcm[:, 12 * 1152:])
+    assert b.status() == 0
+    for s in range(S):
+        enc = O.OracleEncoder(O.default_control(**kws[s]))
+        want = b"".join(enc.encode_f32(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F))
+        assert got[s] + got2[s] == want, "stream %d" % s
     b.close()
 
 

@@ -53,6 +53,19 @@ def test_block_switching_streams_byte_identical(name, kw, sr, rho, nfr):
     assert len(a) > 0 and a == b
 
 
+def test_float_input_byte_identical():
+    """L3_audio_encode takes float at int16 scale; non-integral samples must not be rounded"""
+    kw = dict(bitrate=64, short_block_threshold=99999)
+    nfr = 60
+    pcm = synth.stream_pcm(17, nfr).astype(np.float32)
+    pcm += np.random.default_rng(5).uniform(-0.49, 0.49, pcm.shape).astype(np.float32)
+    r = O.RefEncoder(O.default_control(**kw), s16=False)
+    o = O.OracleEncoder(O.default_control(**kw))
+    a = b"".join(r.encode_f32(pcm[f * 1152:(f + 1) * 1152]) for f in range(nfr))
+    b = b"".join(o.encode_f32(pcm[f * 1152:(f + 1) * 1152]) for f in range(nfr))
+    assert len(a) > 0 and a == b
+
+
 def test_carried_state_matches_every_frame():
     kw = dict(bitrate=64, short_block_threshold=99999)
     pcm = synth.stream_pcm(3, 40)
