@@ -93,6 +93,8 @@ struct alignas(16) AllocLds {
     AllocPrm P;
     int tabpk[32];                      // per Huffman table: code offset | row stride << 12 | linbits << 20
     unsigned long long candpk[19];      // candidate tables per class of a region's largest value
+    unsigned short r_mf[32];            // pending frames: main-data bytes of the slot ...
+    int r_off[32];                      // ... and offset of its header in the output buffer
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
 #ifdef HX_PROFILE
     unsigned long long prof[64];

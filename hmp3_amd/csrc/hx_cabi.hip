@@ -149,13 +149,14 @@ extern "C" int hx_batch_nstreams(const hx_batch *b) { return b ? b->S : 0; }
 
 extern "C" long long hx_batch_out_stride(const hx_batch *b, int nframes)
 {
-    // a call can flush up to 31 pending frames plus its own; largest MPEG-1 frame is 1441 bytes
+    // nframes new frames plus the images of the frames still pending from earlier calls (their
+    // free space is at most the 511-byte reservoir, so a handful of frames; 4 KB covers them)
     int maxframe = 0;
     for (const HxParams &p : b->params) {
         int fb = p.vbr_flag ? p.vbr_framebytes[p.ivbr_max] : p.framebytes + 1;
         if (fb > maxframe) maxframe = fb;
     }
-    long long n = (long long) (nframes + 2) * maxframe;
+    long long n = (long long) (nframes + 2) * maxframe + 4096;
     return (n + 255) & ~255LL;
 }
 
