@@ -108,6 +108,27 @@ void hx_batch_debug_enable(hx_batch *b, int on);
 /* host-side table generation for the CPU tests (no GPU): see hx_cabi.hip */
 long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *name, void *dst, long long cap);
 
+/* ---- Xing / Info / LAME tag frame (first frame of a file; reference pub/xhead.h) ----
+   Same arguments and return values as the reference functions; the seek-table state that the
+   reference keeps in file statics lives in an hx_xing object. */
+typedef struct hx_xing hx_xing;
+hx_xing *hx_xing_create(void);
+void hx_xing_destroy(hx_xing *x);
+/* xhead.c:255 XingHeader: builds the tag frame into buf, returns its size in bytes (0 = does not fit) */
+int hx_xing_header(hx_xing *x, int samprate, int h_mode, int cr_bit, int original_bit, int flags, int frames,
+                   int bs_bytes, int vbr_scale, const unsigned char *toc, unsigned char *buf,
+                   const unsigned char *buf20, const unsigned char *buf20b, int kbps);
+/* xhead.c:695 XingHeaderTOC: record a seek point; returns how many encode calls to wait for the next one */
+int hx_xing_toc(hx_xing *x, int frames, int bs_bytes);
+/* xhead.c:486 XingHeaderUpdateInfo: final frame / byte counts, TOC, LAME info fields and CRCs; 1 = ok */
+int hx_xing_update_info(hx_xing *x, unsigned frames, int bs_bytes, int vbr_scale, const unsigned char *toc,
+                        unsigned char *buf, const unsigned char *buf20, const unsigned char *buf20b,
+                        unsigned long long samples_audio, unsigned bytes_mp3, unsigned lowpass,
+                        unsigned in_samplerate, unsigned out_samplerate, unsigned short musiccrc);
+/* xhead.c:223 XingHeaderUpdateCRC (MusicCRC), xhead.c:236 XingHeaderBitrateIndex */
+unsigned short hx_xing_update_crc(unsigned short crc, const unsigned char *data, int len);
+int hx_xing_bitrate_index(int mpeg1, int kbps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,25 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
     b.close()
 
 
+@pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc"])
+def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
+    """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
+    reference CLI (tests/golden/cli_*.mp3, tools/make_golden_cli.py)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden_cli as M
+    seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
+    wav, mp3 = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3")
+    M.write_wav(wav, M.case_pcm(name), sr, as_float)
+    exe = os.path.join(root, "hmp3_amd", "hmp3amd")
+    assert os.path.exists(exe), "hmp3_amd/build.sh builds the CLI"
+    r = subprocess.run([exe, wav, mp3] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""

@@ -1,0 +1,61 @@
+"""File-level golden vectors for the CLI: WAVs synthesised by hmp3_amd/synth.py are
+encoded by the REAL reference CLI (oracle/_ref/hmp3, built by `make -C oracle ref`) and the complete
+.mp3 files (tag frame included) are committed under tests/golden/.  Run in the build container:
+    python tools/make_golden_cli.py
+The WAVs themselves are not committed: tests regenerate them from the same seeds."""
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hmp3_amd import synth  # noqa: E402
+
+CASES = {
+    # name: (seed, samples (deliberately not a multiple of 1152), sample rate, float WAV?, bursts, CLI flags)
+    "cli_cbr128_s16_44k": (901, 150000, 44100, False, False, ["-B64"]),
+    "cli_vbr75_f32_48k_hf": (902, 120011, 48000, True, True, ["-V75", "-HF2", "-F19000"]),
+    "cli_cbr192_s16_32k_x1_dc": (903, 70001, 32000, False, True, ["-B96", "-X1", "-S1", "-M0"]),
+}
+
+
+def write_wav(path, pcm_i16, sr, as_float):
+    n = pcm_i16.shape[0]
+    if as_float:
+        data = (pcm_i16.astype(np.float32) / 32768.0).astype("<f4").tobytes()
+        fmt = struct.pack("<HHIIHH", 3, 2, sr, sr * 8, 8, 32)
+    else:
+        data = pcm_i16.astype("<i2").tobytes()
+        fmt = struct.pack("<HHIIHH", 1, 2, sr, sr * 4, 4, 16)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+    return n
+
+
+def case_pcm(name):
+    seed, nsamp, sr, as_float, bursts, flags = CASES[name]
+    nfr = (nsamp + 1151) // 1152
+    return synth.stream_pcm(seed, nfr, sr=sr, rho=0.5, bursts=bursts)[:nsamp]
+
+
+if __name__ == "__main__":
+    ref = os.path.join(ROOT, "oracle", "_ref", "hmp3")
+    gold = os.path.join(ROOT, "tests", "golden")
+    meta = {}
+    for name, (seed, nsamp, sr, as_float, bursts, flags) in CASES.items():
+        with tempfile.TemporaryDirectory() as d:
+            wav, mp3 = os.path.join(d, "in.wav"), os.path.join(d, "out.mp3")
+            write_wav(wav, case_pcm(name), sr, as_float)
+            subprocess.run([ref, wav, mp3] + flags, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            data = open(mp3, "rb").read()
+        open(os.path.join(gold, name + ".mp3"), "wb").write(data)
+        meta[name] = {"bytes": len(data), "flags": flags}
+        print(name, len(data), "bytes")
+    json.dump(meta, open(os.path.join(gold, "cli.json"), "w"), indent=1)
