@@ -422,25 +422,40 @@ extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, i
 {
     (void) mpeg_select;
     if (mono_convert || ec->mode == 3) { set_err("mono is not on the GPU path"); return 0; }
-    if (!(source_bits == 16 || (source_bits == 32 && source_is_float))) { set_err("16-bit or float sources only"); return 0; }
+    if (!(source_bits == 8 || source_bits == 16 || source_bits == 24 || source_bits == 32)) { set_err("8, 16, 24 or 32-bit sources only"); return 0; }
+    if (source_is_float && source_bits != 32) { set_err("float sources are 32-bit"); return 0; }
     if (ec->samprate != 32000 && ec->samprate != 44100 && ec->samprate != 48000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
     int r = hx_enc_L3_audio_encode_init(e, ec);
     if (!r) return 0;
     e->src_bits = source_bits;
     e->src_float = source_is_float;
-    return source_bits == 16 ? 4608 : 9216;
+    return 2304 * (source_bits / 8);
 }
 
 extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out)
 {
     if (e->src_bits == 16) return encode_one(e, pcm, 0, bs_out, 4608);
-    if (e->src_bits == 32) {    // float in [-1, 1) is scaled by 32768 (srcc.cpp:805-808)
-        std::vector<float> t(2304);
+    // every other sample format becomes fp32 at int16 scale exactly as Csrc::sr_convert does it
+    // (srcc.cpp:804-836), little-endian input
+    std::vector<float> t(2304);
+    if (e->src_bits == 32 && e->src_float) {
         const float *f = (const float *) pcm;
         for (int i = 0; i < 2304; i++) t[i] = f[i] * 32768.0f;
-        return hx_enc_L3_audio_encode(e, t.data(), bs_out);
+    } else if (e->src_bits == 32) {
+        const int *s = (const int *) pcm;
+        for (int i = 0; i < 2304; i++) t[i] = (float) (s[i] / 65536.0f);
+    } else if (e->src_bits == 24) {
+        for (int i = 0; i < 2304; i++) {
+            const unsigned char *b = pcm + 3 * i;
+            const int s = (int) (((unsigned) b[2] << 24) | ((unsigned) b[1] << 16) | ((unsigned) b[0] << 8)) >> 8;
+            t[i] = (float) ((float) s / 256.0f);
+        }
+    } else {
+        for (int i = 0; i < 2304; i++) t[i] = (((float) pcm[i]) - 128.0f) * (256.0f);
     }
-    return hx_enc_L3_audio_encode(e, (const float *) pcm, bs_out);
+    HX_IN_OUT x = hx_enc_L3_audio_encode(e, t.data(), bs_out);
+    x.in_bytes = 2304 * (e->src_bits / 8);
+    return x;
 }
 
 extern "C" unsigned hx_enc_get_frames(hx_enc *e) { return e->frames; }

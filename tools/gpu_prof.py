@@ -23,3 +23,5 @@ for k in sorted(names):
 print("  kernel ticks/frame %.0f" % (tot / F))
 ms, n = b.alloc_kernel_ms()
 print("k_alloc ms %.3f (%d calls)" % (ms, n))
+t = prof[:, 31] / F
+print("per-stream kernel ticks/frame: min %.0f  mean %.0f  p95 %.0f  max %.0f" % (t.min(), t.mean(), np.percentile(t, 95), t.max()))

@@ -21,14 +21,28 @@ CASES = {
     "cli_cbr128_s16_44k": (901, 150000, 44100, False, False, ["-B64"]),
     "cli_vbr75_f32_48k_hf": (902, 120011, 48000, True, True, ["-V75", "-HF2", "-F19000"]),
     "cli_cbr192_s16_32k_x1_dc": (903, 70001, 32000, False, True, ["-B96", "-X1", "-S1", "-M0"]),
+    "cli_vbr50_s24_44k": (904, 60007, 44100, 24, False, []),
+    "cli_cbr128_u8_44k": (905, 50003, 44100, 8, False, ["-B64"]),
+    "cli_vbr50_s32_48k": (906, 50003, 48000, 32, False, ["-V50"]),
 }
 
 
 def write_wav(path, pcm_i16, sr, as_float):
     n = pcm_i16.shape[0]
-    if as_float:
+    if as_float is True:
         data = (pcm_i16.astype(np.float32) / 32768.0).astype("<f4").tobytes()
         fmt = struct.pack("<HHIIHH", 3, 2, sr, sr * 8, 8, 32)
+    elif as_float in (8, 24, 32):       # integer PCM of that width; low bits filled so they matter
+        rng = np.random.default_rng(n)
+        if as_float == 8:
+            data = ((pcm_i16.astype(np.int32) >> 8) + 128).astype(np.uint8).tobytes()
+        elif as_float == 24:
+            v = (pcm_i16.astype(np.int32) << 8) + rng.integers(0, 256, pcm_i16.shape)
+            b = v.astype("<i4").tobytes()
+            data = b"".join(b[i:i + 3] for i in range(0, len(b), 4))
+        else:
+            data = ((pcm_i16.astype(np.int64) << 16) + rng.integers(0, 65536, pcm_i16.shape)).astype("<i4").tobytes()
+        fmt = struct.pack("<HHIIHH", 1, 2, sr, sr * 2 * as_float // 8, 2 * as_float // 8, as_float)
     else:
         data = pcm_i16.astype("<i2").tobytes()
         fmt = struct.pack("<HHIIHH", 1, 2, sr, sr * 4, 4, 16)
