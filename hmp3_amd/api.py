@@ -38,7 +38,7 @@ class IntPair(C.Structure):
 EXPORTS = [
     "hx_last_error", "hx_device_count", "hx_default_control",
     "hx_enc_create", "hx_enc_destroy", "hx_enc_L3_audio_encode_init", "hx_enc_L3_audio_encode",
-    "hx_enc_MP3_audio_encode_init", "hx_enc_MP3_audio_encode", "hx_enc_get_bitrate",
+    "hx_enc_MP3_audio_encode_init", "hx_enc_MP3_audio_encode", "hx_enc_L3_audio_encode_Packet", "hx_enc_MP3_audio_encode_Packet", "hx_batch_packet_buffers", "hx_enc_get_bitrate",
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
@@ -73,6 +73,12 @@ def lib():
         L.hx_enc_L3_audio_encode_init.argtypes = [C.c_void_p, C.POINTER(EControl)]
         L.hx_enc_L3_audio_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hx_enc_L3_audio_encode.restype = InOut
+        L.hx_enc_L3_audio_encode_Packet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hx_enc_L3_audio_encode_Packet.restype = InOut
+        L.hx_enc_MP3_audio_encode_Packet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hx_enc_MP3_audio_encode_Packet.restype = InOut
+        L.hx_batch_packet_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_batch_packet_buffers.restype = None
         L.hx_enc_MP3_audio_encode_init.argtypes = [C.c_void_p, C.POINTER(EControl), C.c_int, C.c_int, C.c_int, C.c_int]
         L.hx_enc_MP3_audio_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hx_enc_MP3_audio_encode.restype = InOut
@@ -219,6 +225,14 @@ class Mp3Enc:
         pcm = np.ascontiguousarray(pcm_f32, dtype=np.float32)
         x = lib().hx_enc_L3_audio_encode(self.h, pcm.ctypes.data, self._out)
         return x.in_bytes, bytes(self._out[: x.out_bytes])
+
+    def L3_audio_encode_Packet(self, pcm_f32):
+        """-> (in_bytes, bitstream bytes, packet bytes)"""
+        pcm = np.ascontiguousarray(pcm_f32, dtype=np.float32)
+        pk = (C.c_ubyte * 4096)()
+        nb = (C.c_int * 2)()
+        x = lib().hx_enc_L3_audio_encode_Packet(self.h, pcm.ctypes.data, self._out, pk, nb)
+        return x.in_bytes, bytes(self._out[: x.out_bytes]), bytes(pk[: nb[0]])
 
     def MP3_audio_encode(self, pcm_i16):
         pcm = np.ascontiguousarray(pcm_i16, dtype=np.int16)

@@ -27,6 +27,7 @@ struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
     const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
     unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status; unsigned long long *prof;
+    unsigned char *packet; long long packet_stride; int *packet_bytes;
 };
 __global__ void k_alloc(AllocArgs a);
 
@@ -48,6 +49,7 @@ struct hx_batch {
     HxGlobalTabs *d_gt = nullptr;
     HxStream *d_st = nullptr;
     float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
+    unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
     bool any_dc = false;
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
@@ -160,6 +162,11 @@ extern "C" long long hx_batch_out_stride(const hx_batch *b, int nframes)
     return (n + 255) & ~255LL;
 }
 
+extern "C" void hx_batch_packet_buffers(hx_batch *b, unsigned char *d_packet, long long frame_stride, int *d_packet_bytes)
+{
+    b->pk_buf = d_packet; b->pk_stride = frame_stride; b->pk_bytes = d_packet_bytes;
+}
+
 extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
 {
     b->debug = on != 0;
@@ -201,6 +208,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
     a.msbase = b->d_msbase; a.bt = b->d_bt; a.btprev = b->d_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
+    a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -366,6 +374,8 @@ struct hx_enc {
     std::vector<unsigned char> outbuf;
     unsigned frames = 0, bytes = 0;
     int ave = 0;
+    unsigned char *d_packet = nullptr;  // one reformatted frame (device), allocated on first *_Packet call
+    int *d_packet_bytes = nullptr;
 };
 
 extern "C" hx_enc *hx_enc_create(int device)
@@ -378,6 +388,8 @@ extern "C" hx_enc *hx_enc_create(int device)
 extern "C" void hx_enc_destroy(hx_enc *e)
 {
     if (!e) return;
+    if (e->d_packet) hipFree(e->d_packet);
+    if (e->d_packet_bytes) hipFree(e->d_packet_bytes);
     hx_batch_destroy(e->b);
     delete e;
 }
@@ -415,6 +427,41 @@ extern "C" HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigne
 {
     // float at int16 scale (pub/mp3enc.h:90-98), taken as is: the polyphase kernel reads fp32
     return encode_one(e, pcm, 1, bs_out, 9216);
+}
+
+// CMp3Enc::L3_audio_encode_Packet / MP3_audio_encode_Packet (pub/mp3enc.h:110-131): the normal
+// bitstream in bs_out (may be NULL) plus this call's frame as a self-contained packet
+// (nbytes_out[0] bytes, nbytes_out[1] = 0); packet may be NULL.
+extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out);
+static HX_IN_OUT encode_packet(hx_enc *e, const void *pcm, int mp3_entry, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2])
+{
+    std::vector<unsigned char> scratch;
+    if (!bs_out) { scratch.resize(e->outbuf.size()); bs_out = scratch.data(); }
+    if (packet) {
+        hipSetDevice(e->device);
+        if (!e->d_packet) { hipMalloc((void **) &e->d_packet, 2048); hipMalloc((void **) &e->d_packet_bytes, sizeof(int)); }
+        hx_batch_packet_buffers(e->b, e->d_packet, 2048, e->d_packet_bytes);
+    }
+    HX_IN_OUT x = mp3_entry ? hx_enc_MP3_audio_encode(e, (const unsigned char *) pcm, bs_out) : hx_enc_L3_audio_encode(e, (const float *) pcm, bs_out);
+    if (packet) {
+        int n = 0;
+        hipMemcpy(&n, e->d_packet_bytes, sizeof(int), hipMemcpyDeviceToHost);
+        hipMemcpy(packet, e->d_packet, (size_t) n, hipMemcpyDeviceToHost);
+        nbytes_out[0] = n;
+        nbytes_out[1] = 0;
+        hx_batch_packet_buffers(e->b, nullptr, 0, nullptr);
+    }
+    return x;
+}
+
+extern "C" HX_IN_OUT hx_enc_L3_audio_encode_Packet(hx_enc *e, const float *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2])
+{
+    return encode_packet(e, pcm, 0, bs_out, packet, nbytes_out);
+}
+
+extern "C" HX_IN_OUT hx_enc_MP3_audio_encode_Packet(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2])
+{
+    return encode_packet(e, pcm, 1, bs_out, packet, nbytes_out);
 }
 
 extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, int source_bits, int source_is_float,

@@ -67,6 +67,11 @@ unsigned hx_enc_get_frames(hx_enc *e);                      /* mp3enc.cpp:3484 *
 HX_INT_PAIR hx_enc_get_frames_bytes(hx_enc *e);             /* mp3enc.cpp:3512 */
 void hx_enc_info_ec(hx_enc *e, HX_E_CONTROL *ec);           /* mp3enc.cpp:3491 */
 void hx_enc_info_head(hx_enc *e, HX_MPEG_HEAD *head);       /* mp3enc.cpp:3498 */
+/* pub/mp3enc.h:110-131 *_Packet: also return this call's frame as a self-contained ("reformatted")
+   packet: header, side info with main_data_begin 0, unpadded main data; nbytes_out[0] = its size,
+   nbytes_out[1] = 0.  bs_out or packet may be NULL. */
+HX_IN_OUT hx_enc_L3_audio_encode_Packet(hx_enc *e, const float *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
+HX_IN_OUT hx_enc_MP3_audio_encode_Packet(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 void hx_enc_info_string(hx_enc *e, char *s);                /* mp3enc.cpp:3505, <= 80 chars */
 
 /* ---- batched encode (N independent streams) ---- */
@@ -92,6 +97,10 @@ int hx_batch_encode_f32_device(hx_batch *b, const float *d_pcm, int nframes, uns
                                long long out_stride, int *d_out_bytes, void *stream);
 int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
                              long long out_stride, int *out_bytes);
+/* optional packet outputs of the batched calls: d_packet [nstreams][nframes][frame_stride] bytes,
+   d_packet_bytes [nstreams][nframes]; frame_stride >= 36 + largest main data of a frame (2048 is
+   always enough).  NULL switches them off.  Applies to the calls that follow. */
+void hx_batch_packet_buffers(hx_batch *b, unsigned char *d_packet, long long frame_stride, int *d_packet_bytes);
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
    there).  0 = healthy.  Synchronises. */
 int hx_batch_status(hx_batch *b);

@@ -148,6 +148,8 @@ typedef struct hxo_encoder {
     hxo_params p;
     hxo_state s;
     hxo_frame_debug *dbg;
+    unsigned char *packet;      /* set for the duration of hxo_encode_frame_packet */
+    int packet_bytes;
 } hxo_encoder;
 void hxo_set_debug(hxo_encoder *e, hxo_frame_debug *d);
 int hxo_sizeof_frame_debug(void);
@@ -162,6 +164,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec);
 int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out);
 /* 16-bit entry (MP3_audio_encode with source_bits=16, mp3enc.cpp:2812; srcc.cpp:824-828) */
 int hxo_encode_frame_s16(hxo_encoder *e, const int16_t *pcm, unsigned char *out);
+int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out, unsigned char *packet, int *packet_bytes);
 unsigned hxo_frames_out(const hxo_encoder *e);
 unsigned hxo_bytes_out(const hxo_encoder *e);
 void hxo_default_control(hxo_control *ec);      /* test/tomp3.cpp:357-384 */

@@ -438,7 +438,7 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
     const hxo_params *p = &e->p;
     hxo_bitw w;
     unsigned char *out0 = out;
-    int bytes, pad = 0, ms, ibr = 0, mf, bytesout;
+    int bytes, raw_bytes, pad = 0, ms, ibr = 0, mf, bytesout;
 
     input_filter(e, pcm);
     if (!p->vbr_flag) {
@@ -475,11 +475,22 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         s->br_index_buf[s->side_p1] = (unsigned char) ibr;
         s->frame_mf_bytes[s->side_p1] = p->vbr_main_framebytes[ibr];
     }
+    raw_bytes = bytes;
     if (bytes < s->byte_min) {
         memset(s->main_buf + s->main_p1 + bytes, 0, s->byte_min - bytes);
         bytes = s->byte_min;
     }
     hxo_pack_side(s->side_buf[s->side_p1], p->h_mode, s->scfsi, s->gr);
+    if (e->packet) {    /* reformatted frame of the *_Packet entry points (mp3enc.cpp:3066-3074, :2944-2951):
+                           this frame's header, side info (main_data_begin still 0) and unpadded main data */
+        unsigned char *q = e->packet;
+        q[0] = p->head[0]; q[1] = p->head[1]; q[2] = p->head[2]; q[3] = p->head[3];
+        if (pad) q[2] |= 2;     /* L3_pack_head in both variants: the VBR packet keeps the nominal bitrate index */
+        q[3] = (unsigned char) ((q[3] & 0xCF) | ((ms + ms) << 4));
+        memcpy(q + 4, s->side_buf[s->side_p1], 32);
+        memcpy(q + 36, s->main_buf + s->main_p1, (size_t) raw_bytes);
+        e->packet_bytes = 36 + raw_bytes;
+    }
     s->main_tot += bytes;
     s->main_bytes += bytes;
     s->main_p1 += bytes;
@@ -517,6 +528,18 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         s->main_p0 = 0;
     }
     return bytesout;
+}
+
+/* CMp3Enc::L3_audio_encode_Packet: also returns the frame as a self-contained packet */
+int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out, unsigned char *packet, int *packet_bytes)
+{
+    int n;
+    e->packet = packet;
+    e->packet_bytes = 0;
+    n = hxo_encode_frame(e, pcm, out);
+    e->packet = 0;
+    *packet_bytes = e->packet_bytes;
+    return n;
 }
 
 int hxo_encode_frame_s16(hxo_encoder *e, const int16_t *pcm, unsigned char *out)

@@ -52,6 +52,7 @@ def lib():
         _lib.hxo_init.argtypes = [C.c_void_p, C.POINTER(Control)]
         _lib.hxo_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.hxo_encode_frame_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.hxo_encode_frame_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.hxo_mblog.argtypes = [C.c_float]
         _lib.hxo_mbexp.argtypes = [C.c_int]
         _lib.hxo_mbexp.restype = C.c_float
@@ -72,6 +73,7 @@ def ref():
             _ref.ref_init_s16.argtypes = [C.c_void_p, C.POINTER(Control)]
             _ref.ref_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
             _ref.ref_encode_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            _ref.ref_encode_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             _ref.ref_encode_stream_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]
             _ref.ref_encode_stream_s16.restype = C.c_long
             _ref.ref_dump.argtypes = [C.c_void_p, C.c_void_p]
@@ -116,6 +118,14 @@ class OracleEncoder:
         n = self.l.hxo_encode_frame(self.h, frame.ctypes.data, self.out)
         return bytes(self.out[:n])
 
+    def encode_packet(self, frame):
+        """-> (bitstream bytes, reformatted packet bytes) of L3_audio_encode_Packet"""
+        frame = np.ascontiguousarray(frame, dtype=np.float32)
+        pk = (C.c_ubyte * 4096)()
+        nb = C.c_int(0)
+        n = self.l.hxo_encode_frame_packet(self.h, frame.ctypes.data, self.out, pk, C.byref(nb))
+        return bytes(self.out[:n]), bytes(pk[:nb.value])
+
     def __del__(self):
         try:
             self.l.hxo_free(self.h)
@@ -142,6 +152,13 @@ class RefEncoder:
         frame = np.ascontiguousarray(frame, dtype=np.float32)
         n = self.r.ref_encode(self.h, frame.ctypes.data, self.out)
         return bytes(self.out[:n])
+
+    def encode_packet(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.float32)
+        pk = (C.c_ubyte * 4096)()
+        nb = (C.c_int * 2)()
+        n = self.r.ref_encode_packet(self.h, frame.ctypes.data, self.out, pk, nb)
+        return bytes(self.out[:n]), bytes(pk[:nb[0]])
 
     def dump(self):
         d = RefDump()

@@ -95,6 +95,21 @@ def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=64), dict(vbr_mnr=60)], ids=["cbr128", "vbr60"])
+def test_packet_variant_matches_oracle(kw):
+    """CMp3Enc::L3_audio_encode_Packet: bitstream plus the self-contained packet of every frame"""
+    nfr = 30
+    pcm = synth.stream_pcm(23, nfr, bursts=True).astype(np.float32)
+    e = api().Mp3Enc()
+    assert e.L3_audio_encode_init(api().default_control(**kw)) == 9216
+    o = O.OracleEncoder(O.default_control(**kw))
+    for f in range(nfr):
+        nin, bs, pk = e.L3_audio_encode_Packet(pcm[f * 1152:(f + 1) * 1152])
+        want_bs, want_pk = o.encode_packet(pcm[f * 1152:(f + 1) * 1152])
+        assert nin == 9216 and bs == want_bs and pk == want_pk, "frame %d" % f
+    e.close()
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""

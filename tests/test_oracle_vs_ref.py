@@ -66,6 +66,19 @@ def test_float_input_byte_identical():
     assert len(a) > 0 and a == b
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=64), dict(vbr_mnr=60)], ids=["cbr128", "vbr60"])
+def test_packet_variant_byte_identical(kw):
+    """L3_audio_encode_Packet: bitstream and the reformatted (self-contained) frame"""
+    nfr = 50
+    pcm = synth.stream_pcm(23, nfr, bursts=True).astype(np.float32)
+    r = O.RefEncoder(O.default_control(**kw), s16=False)
+    o = O.OracleEncoder(O.default_control(**kw))
+    for f in range(nfr):
+        a = r.encode_packet(pcm[f * 1152:(f + 1) * 1152])
+        b = o.encode_packet(pcm[f * 1152:(f + 1) * 1152])
+        assert a == b and len(a[1]) >= 36, "frame %d" % f
+
+
 def test_carried_state_matches_every_frame():
     kw = dict(bitrate=64, short_block_threshold=99999)
     pcm = synth.stream_pcm(3, 40)
