@@ -65,6 +65,7 @@ typedef struct {
     int nband, nsb, nsb_limit, nsb_limitMS[2], band_limit, band_limit_stereo;
     int framebytes, remainder, divisor, main_framebytes, side_bytes, sf_bit_max, AveTargetBits;
     int ms_flag, hf_flag, vbr_flag, short_block_threshold, filter_dc;
+    int nchan;                  /* 1 = mono (mode 3), 2 = stereo / joint stereo */
     float filter_alpha;
     int ivbr_min, ivbr_max, vbr_main_framebytes[16], vbr_framebytes[16], vbr_pool_target;
     int initialMNR, test1, taperNT[22];
@@ -201,7 +202,7 @@ int  hxo_pack_sf_long_scfsi(hxo_bitw *w, int sf_save[21], const hxo_scalefact *s
 int  hxo_pack_sf_long(hxo_bitw *w, const hxo_scalefact *sf);      /* l3pack.c:157 */
 int  hxo_pack_sf_short(hxo_bitw *w, const hxo_scalefact *sf);     /* l3pack.c:218 */
 int  hxo_pack_huff(hxo_bitw *w, const hxo_gr *g, const int *ix, const unsigned char *sign);  /* l3pack.c:946 */
-void hxo_pack_side(unsigned char out[32], int mode, const int scfsi[2], hxo_gr gr[2][2]);      /* l3pack.c:1123 */
+void hxo_pack_side(unsigned char out[32], int mode, const int scfsi[2], hxo_gr gr[2][2], int nchan);      /* l3pack.c:1123 */
 
 #ifdef __cplusplus
 }

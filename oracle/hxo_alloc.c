@@ -950,7 +950,7 @@ void hxo_bitallo_long(hxo_encoder *e, float xr[2][576], hxo_sigmask sm[2][36],
     } else if (block_type == 3) {
         st->MNR = (st->MNR + p->initialMNR) >> 1;
         st->MNR = HXO_MIN(st->MNR, p->initialMNR + 500);
-        memset(st->ix, 0, 2 * 576 * sizeof(int));
+        memset(st->ix, 0, p->nchan * 576 * sizeof(int));
     }
     if (block_type == 2) {
         int MNR0 = st->MNR;
@@ -965,7 +965,7 @@ void hxo_bitallo_long(hxo_encoder *e, float xr[2][576], hxo_sigmask sm[2][36],
     }
     b->ms_flag = ms_flag;
     b->xr = xr; b->signx = st->signx; b->ix = st->ix;
-    b->nchan = 2;
+    b->nchan = p->nchan;
     b->maxBits = HXO_MIN(4000 * b->nchan, max_bits);
     b->minTargetBits = min_bits;
     if (b->minTargetBits < 0) b->minTargetBits = 0;

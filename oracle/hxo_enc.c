@@ -37,7 +37,7 @@ static void gen_vbr_table(hxo_params *p, int max_tot_bitrate)
     for (i = 1; i < 15; i++) {
         int mb = 144000 * br_mpeg1_l3[i] / p->samprate;
         p->vbr_framebytes[i] = mb;
-        p->vbr_main_framebytes[i] = mb - 4 - 32;
+        p->vbr_main_framebytes[i] = mb - 4 - p->side_bytes;
     }
     p->vbr_framebytes[15] = p->vbr_main_framebytes[15] = 9999999;
     p->vbr_pool_target = 256;
@@ -47,7 +47,7 @@ static void gen_vbr_table(hxo_params *p, int max_tot_bitrate)
     }
     p->ivbr_max = i;
     p->ivbr_min = 1;
-    p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / (2 * 2)) - p->sf_bit_max;
+    p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / (2 * p->nchan)) - p->sf_bit_max;
 }
 
 /* mp3enc.cpp:220-870 + setup.c:189-292 + bitallo3.cpp:288-480 */
@@ -95,15 +95,16 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     h_id = k >> 2;
     p->h_sr_index = k & 3;
     if (h_id != 1) return 0;                /* MPEG-2 rates: out of scope */
-    if (ec.mode != 0 && ec.mode != 1) return 0;     /* dual / mono: out of scope */
+    if (ec.mode == 2) return 0;             /* dual channel (CBitAllo1): out of scope */
     p->h_mode = ec.mode;
+    p->nchan = (ec.mode == 3) ? 1 : 2;
     mode_ext = 0;
     if (p->h_mode == 1) mode_ext = ec.nsbstereo / 4 - 1;
     if (mode_ext < 0) mode_ext = 0;
     if (mode_ext > 3) mode_ext = 3;
     bitrate = ec.bitrate;
     if (bitrate < 8) bitrate = 8;
-    bitrate = 2 * bitrate;
+    if (ec.mode != 3) bitrate = 2 * bitrate;
     if (bitrate > 320) bitrate = 320;
     p->h_br_index = 0;
     for (i = 1; br_mpeg1_l3[i] >= 0; i++) if (br_mpeg1_l3[i] == bitrate) p->h_br_index = i;
@@ -133,11 +134,11 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     p->divisor = p->samprate;
     p->framebytes = 144000 * p->totbitrate / p->divisor;
     p->remainder = (144000 * p->totbitrate) % p->divisor;
-    p->side_bytes = 32;
+    p->side_bytes = (p->h_mode == 3) ? 17 : 32;
     p->main_framebytes = p->framebytes - 4 - p->side_bytes;
     p->sf_bit_max = 3 * (6 * 4 + 6 * 3);
     p->AveTargetBits = 8 * p->main_framebytes / 2;
-    p->AveTargetBits >>= 1;
+    if (p->h_mode != 3) p->AveTargetBits >>= 1;
     p->AveTargetBits -= p->sf_bit_max;
 
     nsb_user_flag = 0;
@@ -161,7 +162,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         /* calc_freq_limit_L3 (mp3enc.cpp:899-935) */
         static const float factor[4] = {1.1f, 1.333f, 1.0f, 1.0f};
         float chan_bitrate = (float) p->totbitrate;
-        chan_bitrate = (float) (0.5 * chan_bitrate);
+        if (p->h_mode != 3) chan_bitrate = (float) (0.5 * chan_bitrate);
         chan_bitrate = factor[p->h_mode] * chan_bitrate;
         freq_limit = (int) (187.97 * chan_bitrate);
     }
@@ -206,13 +207,13 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     }
     if (is_flag) return 0;                  /* intensity stereo (CBitAllo1): out of scope */
     p->vbr_flag = ec.vbr_flag;
-    if (ec.vbr_flag) gen_vbr_table(p, 2 * ec.vbr_br_limit);
+    if (ec.vbr_flag) gen_vbr_table(p, (ec.mode == 3 ? 1 : 2) * ec.vbr_br_limit);
     if (ec.vbr_flag) {
         p->initialMNR = 10 * ec.vbr_mnr;
         if (p->initialMNR < 210) p->initialMNR = 210;
         if (p->initialMNR > 1500) p->initialMNR = 1500;
     } else {
-        tmp = p->totbitrate / 2;
+        tmp = p->totbitrate / p->nchan;
         p->initialMNR = 125 * (tmp - 32) / 8;
         if (p->initialMNR < 0) p->initialMNR = 0;
         if (p->initialMNR > 1000) p->initialMNR = 1000;
@@ -272,13 +273,14 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     /* echoed control (mp3enc.cpp:839-866) */
     p->ec = ec;
     p->ec.mode = p->h_mode;
-    p->ec.bitrate = p->totbitrate / 2;
+    p->ec.bitrate = p->totbitrate;
+    if (p->h_mode != 3) p->ec.bitrate /= 2;
     p->ec.samprate = p->samprate;
     p->ec.nsbstereo = 32;
     p->ec.freq_limit = ec.hf_flag ? ec.freq_limit : p->nsb_limit * (p->samprate / 64);
     p->ec.nsb_limit = p->nsb_limit;
     p->ec.layer = 3;
-    return 2 * 4 * 1152;
+    return p->nchan * 4 * 1152;
 }
 
 /* filter2.c:80-153: shift history, store newest first, optional one-pole DC blocker */
@@ -289,6 +291,15 @@ static void input_filter(hxo_encoder *e, const float *pcm)
     float *x = s->buf[0] + 1152, *y = s->buf[1] + 1152, t;
     int i;
     memmove(x, s->buf[0], 2192 * sizeof(float));
+    if (p->nchan == 1) {        /* filter2.c:96-121, one channel */
+        if (!p->filter_dc) { for (i = 0; i < 1152; i++) *--x = pcm[i]; }
+        else {
+            float alpha = p->filter_alpha, d = s->dc[0];
+            for (i = 0; i < 1152; i++) { t = (float) (pcm[i] - d); d = d + alpha * t; *--x = t; }
+            s->dc[0] = d;
+        }
+        return;
+    }
     memmove(y, s->buf[1], 2192 * sizeof(float));
     if (!p->filter_dc) {
         for (i = 0; i < 2304; i += 2) { *--x = pcm[i]; *--y = pcm[i + 1]; }
@@ -325,7 +336,7 @@ static void transform_granule(hxo_encoder *e, int igr)
     hxo_state *s = &e->s;
     const hxo_params *p = &e->p;
     int ch, prev = (s->igrx - 1) & 3, ahead = (s->igrx + 2) & 3, bt = s->block_type[igr];
-    for (ch = 0; ch < 2; ch++) {
+    for (ch = 0; ch < p->nchan; ch++) {
         hxo_freq_invert(s->sample[ch][s->igrx], p->nsb_limitMS[0]);
         if (bt != 2) {
             hxo_hybrid_long(p, s->sample[ch][prev], s->sample[ch][s->igrx], s->xr[igr][ch], bt,
@@ -431,6 +442,65 @@ static int encode_joint(hxo_encoder *e, hxo_bitw *w)
     return ms;
 }
 
+/* mp3enc.cpp:1675-1749 encode_singleB: one channel, no M/S */
+static int encode_single(hxo_encoder *e, hxo_bitw *w)
+{
+    hxo_state *s = &e->s;
+    const hxo_params *p = &e->p;
+    int igr, bits, bit_pool, bit_min, bit_max, ba_bit_min, ba_bit_max, ba_min, ba_max, shortblock_frame;
+
+    bit_pool = s->byte_pool << 2;
+    bit_max = s->byte_max << 2;
+    bit_min = s->byte_min << 2;
+    ba_bit_max = bit_max;
+    if (ba_bit_max > 4095) ba_bit_max = 4095;
+    ba_bit_min = bit_min;
+    ba_bit_max -= p->sf_bit_max;
+    ba_bit_min -= p->sf_bit_max;
+    ba_min = ba_bit_min;
+    ba_max = ba_bit_max;
+
+    blocktype_select(e, 0);
+    transform_granule(e, 0);
+    blocktype_select(e, 1);
+    transform_granule(e, 1);
+    shortblock_frame = (s->block_type[0] == 2) | (s->block_type[1] == 2);
+    if (e->dbg) {
+        e->dbg->ms = 0; e->dbg->ms_metric[0] = e->dbg->ms_metric[1] = 0;
+        e->dbg->byte_pool = s->byte_pool;
+        memcpy(e->dbg->xr_pre, s->xr, sizeof(s->xr));
+        for (igr = 0; igr < 2; igr++) e->dbg->block_type[igr] = s->block_type[igr];
+    }
+    for (igr = 0; igr < 2; igr++) {
+        int bt = s->block_type[igr];
+        hxo_gr *g = &s->gr[igr][0];
+        if (bt != 2) hxo_psy_long(p, s->xr[igr][0], s->ecsave[0], s->sig_mask[0], bt);
+        else hxo_psy_short(p, s->xr[igr][0], s->ecsave[0], s->sig_mask[0], s->block_type_prev[igr]);
+        g->block_type = bt;
+        hxo_bitallo_long(e, s->xr[igr], s->sig_mask, ba_min, p->AveTargetBits, ba_max, bit_pool, s->sf[igr], s->gr[igr], 0);
+        if (e->dbg) {
+            int i;
+            memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
+            memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+            for (i = 0; i < 22; i++) e->dbg->sf[igr][0][i] = s->sf[igr][0].l[i];
+        }
+        bits = 0;
+        g->scalefac_compress = 0;
+        if (shortblock_frame) {
+            s->scfsi[0] = 0;
+            if (g->aux_not_null)
+                g->scalefac_compress = (bt == 2) ? hxo_pack_sf_short(w, &s->sf[igr][0]) : hxo_pack_sf_long(w, &s->sf[igr][0]);
+        } else {
+            g->scalefac_compress = hxo_pack_sf_long_scfsi(w, s->sf_save[0], &s->sf[igr][0], igr, &s->scfsi[0], g->aux_not_null);
+        }
+        if (g->aux_bits) bits = hxo_pack_huff(w, g, s->ix[0], s->signx[0]);
+        ba_min += ba_bit_min + p->sf_bit_max - bits;
+        ba_max += ba_bit_max + p->sf_bit_max - bits;
+        g->part2_3_length = bits;
+    }
+    return 0;
+}
+
 /* mp3enc.cpp:2230-2333 (CBR) and :2106-2226 (VBR) */
 int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
 {
@@ -456,7 +526,7 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         s->byte_min = p->vbr_main_framebytes[p->ivbr_min] + s->byte_pool - 511;
     }
     hxo_bw_init(&w, s->main_buf + s->main_p1);
-    ms = encode_joint(e, &w);
+    ms = (p->nchan == 2) ? encode_joint(e, &w) : encode_single(e, &w);
     s->last_ms = ms;
     s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms);
     bytes = hxo_bw_flush(&w);
@@ -480,16 +550,16 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         memset(s->main_buf + s->main_p1 + bytes, 0, s->byte_min - bytes);
         bytes = s->byte_min;
     }
-    hxo_pack_side(s->side_buf[s->side_p1], p->h_mode, s->scfsi, s->gr);
+    hxo_pack_side(s->side_buf[s->side_p1], p->h_mode, s->scfsi, s->gr, p->nchan);
     if (e->packet) {    /* reformatted frame of the *_Packet entry points (mp3enc.cpp:3066-3074, :2944-2951):
                            this frame's header, side info (main_data_begin still 0) and unpadded main data */
         unsigned char *q = e->packet;
         q[0] = p->head[0]; q[1] = p->head[1]; q[2] = p->head[2]; q[3] = p->head[3];
         if (pad) q[2] |= 2;     /* L3_pack_head in both variants: the VBR packet keeps the nominal bitrate index */
         q[3] = (unsigned char) ((q[3] & 0xCF) | ((ms + ms) << 4));
-        memcpy(q + 4, s->side_buf[s->side_p1], 32);
-        memcpy(q + 36, s->main_buf + s->main_p1, (size_t) raw_bytes);
-        e->packet_bytes = 36 + raw_bytes;
+        memcpy(q + 4, s->side_buf[s->side_p1], p->side_bytes);
+        memcpy(q + 4 + p->side_bytes, s->main_buf + s->main_p1, (size_t) raw_bytes);
+        e->packet_bytes = 4 + p->side_bytes + raw_bytes;
     }
     s->main_tot += bytes;
     s->main_bytes += bytes;
@@ -511,8 +581,8 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         out += 4;
         s->side_buf[s->side_p0][0] = (unsigned char) (main_data_begin >> 1);
         s->side_buf[s->side_p0][1] |= (main_data_begin & 1) << 7;
-        memmove(out, s->side_buf[s->side_p0], 32);
-        out += 32;
+        memmove(out, s->side_buf[s->side_p0], p->side_bytes);
+        out += p->side_bytes;
         memmove(out, s->main_buf + s->main_p0, mf);
         out += mf;
         s->main_bytes -= mf;
@@ -545,8 +615,8 @@ int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out
 int hxo_encode_frame_s16(hxo_encoder *e, const int16_t *pcm, unsigned char *out)
 {
     float f[2304];
-    int i;
-    for (i = 0; i < 2304; i++) f[i] = (float) pcm[i];
+    int i, n = 1152 * e->p.nchan;
+    for (i = 0; i < n; i++) f[i] = (float) pcm[i];
     return hxo_encode_frame(e, f, out);
 }
 

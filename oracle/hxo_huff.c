@@ -369,17 +369,16 @@ int hxo_pack_huff(hxo_bitw *w, const hxo_gr *g, const int *ix, const unsigned ch
 }
 
 /* l3pack.c:1123-1187 (stereo: 32 bytes; main_data_begin left 0, patched at emit time) */
-void hxo_pack_side(unsigned char out[32], int mode, const int scfsi[2], hxo_gr gr[2][2])
+void hxo_pack_side(unsigned char out[32], int mode, const int scfsi[2], hxo_gr gr[2][2], int nchan)
 {
     hxo_bitw w;
     int igr, ch;
-    (void) mode;
     hxo_bw_init(&w, out);
     hxo_bw_put(&w, 0, 9);
-    hxo_bw_put(&w, 0, 3);
-    for (ch = 0; ch < 2; ch++) hxo_bw_put(&w, scfsi[ch], 4);
+    hxo_bw_put(&w, 0, mode == 3 ? 5 : 3);       /* private bits: 5 in a mono frame (17-byte side info) */
+    for (ch = 0; ch < nchan; ch++) hxo_bw_put(&w, scfsi[ch], 4);
     for (igr = 0; igr < 2; igr++)
-        for (ch = 0; ch < 2; ch++) {
+        for (ch = 0; ch < nchan; ch++) {
             const hxo_gr *g = &gr[igr][ch];
             hxo_bw_put(&w, g->part2_3_length, 12);
             hxo_bw_put(&w, g->big_values, 9);

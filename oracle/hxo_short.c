@@ -518,7 +518,7 @@ int hxo_bitallo_short(hxo_encoder *e, float xr[2][576], hxo_sigmask smarg[2][36]
     e->s.s_call_count++;
     b->ms_flag = ms_flag;
     b->xr = (float (*)[3][192]) xr;
-    b->nchan = 2;
+    b->nchan = p->nchan;
     b->nsf[0] = b->nsf[1] = p->nsfs;
     b->maxBits = HXO_MIN(4000 * b->nchan, max_bits);
     b->minTargetBits = min_bits;

@@ -53,6 +53,29 @@ def test_block_switching_streams_byte_identical(name, kw, sr, rho, nfr):
     assert len(a) > 0 and a == b
 
 
+MONO_CASES = [
+    ("mono_cbr64", dict(bitrate=64, mode=3), 44100),
+    ("mono_vbr50", dict(mode=3), 44100),
+    ("mono_cbr96_48k", dict(bitrate=96, mode=3, samprate=48000), 48000),
+    ("mono_cbr48_32k_long", dict(bitrate=48, mode=3, samprate=32000, short_block_threshold=99999), 32000),
+    ("mono_cbr160", dict(bitrate=160, mode=3), 44100),
+    ("mono_vbr100_hf_48k", dict(mode=3, vbr_mnr=100, hf_flag=3, samprate=48000, freq_limit=19000), 48000),
+    ("mono_cbr64_dc", dict(bitrate=64, mode=3, filter_select=1), 44100),
+]
+
+
+@pytest.mark.parametrize("name,kw,sr", MONO_CASES, ids=[c[0] for c in MONO_CASES])
+def test_mono_streams_byte_identical(name, kw, sr):
+    """mode 3 (encode_singleB, 17-byte side info), block switching on unless disabled"""
+    nfr = 100
+    pcm = synth.stream_pcm(31, nfr, sr=sr, bursts=True)[:, 0].copy()
+    r = O.RefEncoder(O.default_control(**kw))
+    o = O.OracleEncoder(O.default_control(**kw))
+    a = b"".join(r.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(nfr))
+    b = b"".join(o.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(nfr))
+    assert len(a) > 0 and a == b
+
+
 def test_float_input_byte_identical():
     """L3_audio_encode takes float at int16 scale; non-integral samples must not be rounded"""
     kw = dict(bitrate=64, short_block_threshold=99999)
