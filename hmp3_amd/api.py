@@ -158,7 +158,9 @@ class Batch:
         """pcm: int16 (or float32 at int16 scale) [n, nframes*1152, 2] -> list of bytes per stream"""
         f32 = np.asarray(pcm).dtype == np.float32
         pcm = np.ascontiguousarray(pcm, dtype=np.float32 if f32 else np.int16)
-        assert pcm.shape[0] == self.n and pcm.shape[2] == 2 and pcm.shape[1] % 1152 == 0
+        if pcm.ndim == 2:
+            pcm = pcm[:, :, None]           # mono batch: [n, samples]
+        assert pcm.shape[0] == self.n and pcm.shape[2] in (1, 2) and pcm.shape[1] % 1152 == 0
         nfr = pcm.shape[1] // 1152
         stride = self.out_stride(nfr)
         out = np.zeros((self.n, stride), dtype=np.uint8)

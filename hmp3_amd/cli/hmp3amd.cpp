@@ -2,7 +2,7 @@
 // Same command line, encode loop and output file as the reference CLI (SURVEY §8 f1/f2;
 // reference test/tomp3.cpp:336-602 main, :645-1088 ff_encode): Xing/Info tag frame first, audio
 // frames, four frames of silence behind the input, drain until every submitted frame is out, then
-// the tag is completed in place.  Accepted here: RIFF/WAVE, stereo, 8/16/24/32-bit PCM or 32-bit float,
+// the tag is completed in place.  Accepted here: RIFF/WAVE, mono or stereo, 8/16/24/32-bit PCM or 32-bit float,
 // 32 / 44.1 / 48 kHz (what the GPU path encodes); everything else fails like an unsupported file.
 #include <cstdint>
 #include <cstdio>
@@ -111,13 +111,14 @@ int main(int argc, char **argv)
     if (indatasize == 0) { fprintf(stderr, "\n INPUT FILE CONTAINS NO AUDIO\n"); return 1; }
     fprintf(stderr, "\n pcm file:  channels = %d  bits = %d,  rate = %d  type = %d", wi.channels, wi.bits, wi.rate, wi.type);
     const bool is_float = wi.type == 3;
-    if (wi.channels != 2 || !((wi.type == 1 && (wi.bits == 8 || wi.bits == 16 || wi.bits == 24 || wi.bits == 32)) || (is_float && wi.bits == 32)) ||
+    if ((wi.channels != 1 && wi.channels != 2) || !((wi.type == 1 && (wi.bits == 8 || wi.bits == 16 || wi.bits == 24 || wi.bits == 32)) || (is_float && wi.bits == 32)) ||
         (wi.rate != 32000 && wi.rate != 44100 && wi.rate != 48000)) {
-        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes stereo 8/16/24/32-bit PCM or 32-bit float input at 32 / 44.1 / 48 kHz.\n");
+        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes mono or stereo 8/16/24/32-bit PCM or 32-bit float input at 32 / 44.1 / 48 kHz.\n");
         return 1;
     }
     if (ec.mode < 0) ec.mode = 0;
-    if (ec.mode == 3) ec.mode = 1;
+    if (wi.channels == 1) ec.mode = 3;
+    else if (ec.mode == 3) { fprintf(stderr, "\n UNSUPPORTED: down-mixing a stereo file to mono (-M3) is not on the GPU path\n"); return 1; }
     ec.samprate = wi.rate;
 
     hx_enc *enc = hx_enc_create(0);

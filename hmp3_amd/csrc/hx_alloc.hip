@@ -33,6 +33,7 @@ struct AllocPrm {
     float rnBand_l[22];
     int nsfs, nbmax_s;
     struct { int npart; } psyS;
+    int nchan, side_bytes;              // 1 / 17 for a mono stream (mode 3), 2 / 32 otherwise
 };
 
 struct alignas(16) AllocLds {
@@ -1205,7 +1206,7 @@ __device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
 {
     PROF_CNT(22);
     int bits = count_bits_ch(L, p, 0, ncb[0]);
-    bits += count_bits_ch(L, p, 1, ncb[1]);
+    if (p->nchan == 2) bits += count_bits_ch(L, p, 1, ncb[1]);
     SYNC();
     return bits;
 }

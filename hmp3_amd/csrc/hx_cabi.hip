@@ -14,15 +14,15 @@
 // kernels (hx_front.hip / hx_alloc.hip)
 #define K1_GPB 14
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
-                            const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf);
-__global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S);
+                            const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan);
+__global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S, int nchan);
 __global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total);
 __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
                              int *dbg_metric, int NG, int total);
 __global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
 __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                        float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
-__global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf);
+__global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf, int nchan);
 struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
     const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
@@ -52,6 +52,7 @@ struct hx_batch {
     unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
     bool any_dc = false;
+    int nchan = 2;                      // channels of the PCM input, the same for every stream of the batch
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
     unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
     HxFrameDebug *d_dbg = nullptr;
@@ -107,8 +108,10 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         for (size_t i = 0; i < seen.size(); i++) if (memcmp(&seen[i], c, sizeof(HxControl)) == 0) { k = (int) i; break; }
         if (k < 0) {
             HxParams p;
-            if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: MPEG-1 stereo / joint stereo without intensity only)"); delete b; return nullptr; }
+            if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: MPEG-1 mono / stereo / joint stereo without intensity only)"); delete b; return nullptr; }
             if (p.filter_dc) b->any_dc = true;
+            if (b->params.empty()) b->nchan = p.nchan;
+            else if (p.nchan != b->nchan) { set_err("mono and stereo streams cannot share a batch (the PCM layout differs)"); delete b; return nullptr; }
             seen.push_back(*c);
             b->params.push_back(p);
             k = (int) seen.size() - 1;
@@ -137,7 +140,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_btprev, S);
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
-    if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 2304);
+    if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 1152 * b->nchan);
     HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(b->d_gt, &gt, sizeof(gt), hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(b->d_st, st.data(), sizeof(HxStream) * S, hipMemcpyHostToDevice));
@@ -193,8 +196,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     dim3 g1(S, (NG + K1_GPB - 1) / K1_GPB);
     const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
     const float *pcmf = b->any_dc ? b->d_pcmf : d_pcm32;       // fp32 samples the polyphase reads, or null for int16
-    if (b->any_dc) hipLaunchKernelGGL(k_dcfilter, dim3((2 * S + 63) / 64), dim3(64), 0, q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S);
-    hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf);
+    if (b->any_dc) hipLaunchKernelGGL(k_dcfilter, dim3((b->nchan * S + 63) / 64), dim3(64), 0, q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S, b->nchan);
+    hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan);
     int tot = S * 2 * NG * 9;
     hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot);
     tot = S * NG;
@@ -216,7 +219,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     hipLaunchKernelGGL(k_alloc, dim3(S), dim3(64), 0, q, a);
     HIPCHK(hipEventRecord(e1, q));
     b->pending.push_back({e0, e1});
-    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf);
+    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
     HIPCHK(hipGetLastError());
     b->lastNG = NG;
     return 0;
@@ -256,7 +259,7 @@ static int encode_host(hx_batch *b, const void *pcm, int is_f32, int nframes, un
 {
     if (!b) return -1;
     HIPCHK(hipSetDevice(b->device));
-    long long pbytes = (long long) b->S * nframes * 1152 * 2 * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
+    long long pbytes = (long long) b->S * nframes * 1152 * b->nchan * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
     if (pbytes > b->pcm_cap) { if (b->d_pcm) hipFree(b->d_pcm); HIPCHK(hipMalloc((void **) &b->d_pcm, pbytes)); b->pcm_cap = pbytes; }
     if (obytes > b->out_cap) { if (b->d_out) hipFree(b->d_out); HIPCHK(hipMalloc((void **) &b->d_out, obytes)); b->out_cap = obytes; }
     HIPCHK(hipMemcpy(b->d_pcm, pcm, pbytes, hipMemcpyHostToDevice));
@@ -426,7 +429,7 @@ static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned cha
 extern "C" HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out)
 {
     // float at int16 scale (pub/mp3enc.h:90-98), taken as is: the polyphase kernel reads fp32
-    return encode_one(e, pcm, 1, bs_out, 9216);
+    return encode_one(e, pcm, 1, bs_out, 4608 * e->p.nchan);
 }
 
 // CMp3Enc::L3_audio_encode_Packet / MP3_audio_encode_Packet (pub/mp3enc.h:110-131): the normal
@@ -468,7 +471,7 @@ extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, i
                                             int mpeg_select, int mono_convert)
 {
     (void) mpeg_select;
-    if (mono_convert || ec->mode == 3) { set_err("mono is not on the GPU path"); return 0; }
+    if (mono_convert) { set_err("down-mixing to mono is not on the GPU path"); return 0; }
     if (!(source_bits == 8 || source_bits == 16 || source_bits == 24 || source_bits == 32)) { set_err("8, 16, 24 or 32-bit sources only"); return 0; }
     if (source_is_float && source_bits != 32) { set_err("float sources are 32-bit"); return 0; }
     if (ec->samprate != 32000 && ec->samprate != 44100 && ec->samprate != 48000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
@@ -476,32 +479,33 @@ extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, i
     if (!r) return 0;
     e->src_bits = source_bits;
     e->src_float = source_is_float;
-    return 2304 * (source_bits / 8);
+    return 1152 * e->p.nchan * (source_bits / 8);
 }
 
 extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out)
 {
-    if (e->src_bits == 16) return encode_one(e, pcm, 0, bs_out, 4608);
+    const int ns = 1152 * e->p.nchan;       // samples per call
+    if (e->src_bits == 16) return encode_one(e, pcm, 0, bs_out, 2 * ns);
     // every other sample format becomes fp32 at int16 scale exactly as Csrc::sr_convert does it
     // (srcc.cpp:804-836), little-endian input
-    std::vector<float> t(2304);
+    std::vector<float> t(ns);
     if (e->src_bits == 32 && e->src_float) {
         const float *f = (const float *) pcm;
-        for (int i = 0; i < 2304; i++) t[i] = f[i] * 32768.0f;
+        for (int i = 0; i < ns; i++) t[i] = f[i] * 32768.0f;
     } else if (e->src_bits == 32) {
         const int *s = (const int *) pcm;
-        for (int i = 0; i < 2304; i++) t[i] = (float) (s[i] / 65536.0f);
+        for (int i = 0; i < ns; i++) t[i] = (float) (s[i] / 65536.0f);
     } else if (e->src_bits == 24) {
-        for (int i = 0; i < 2304; i++) {
+        for (int i = 0; i < ns; i++) {
             const unsigned char *b = pcm + 3 * i;
             const int s = (int) (((unsigned) b[2] << 24) | ((unsigned) b[1] << 16) | ((unsigned) b[0] << 8)) >> 8;
             t[i] = (float) ((float) s / 256.0f);
         }
     } else {
-        for (int i = 0; i < 2304; i++) t[i] = (((float) pcm[i]) - 128.0f) * (256.0f);
+        for (int i = 0; i < ns; i++) t[i] = (((float) pcm[i]) - 128.0f) * (256.0f);
     }
     HX_IN_OUT x = hx_enc_L3_audio_encode(e, t.data(), bs_out);
-    x.in_bytes = 2304 * (e->src_bits / 8);
+    x.in_bytes = ns * (e->src_bits / 8);
     return x;
 }
 

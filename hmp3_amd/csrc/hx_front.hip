@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
                                                    const HxParams *__restrict__ prm,
                                                    const HxGlobalTabs *__restrict__ gt,
                                                    float *__restrict__ sb, int NG, int SG,
-                                                   const float *__restrict__ pcmf)
+                                                   const float *__restrict__ pcmf, int nchan)
 {
     __shared__ float xs2[2][K1_LDS];
     __shared__ __attribute__((aligned(16))) float wr[512];
@@ -69,10 +69,14 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     const int count = 480 + 576 * ng;
     const HxStream *ss = st + s;
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(ss->cls);
-    const int16_t *src = pcm + (long long) s * nsamp * 2;       // interleaved L R
+    const int16_t *src = pcm + (long long) s * nsamp * nchan;   // interleaved L R (or one channel)
     const long long n0 = 576LL * g0 - 480;                      // sample index of staged slot 0
     const int hist = (g0 == 0) ? 480 : 0;                       // slots that come from the carry
-    if (pcmf) {             // DC-blocked input from k_dcfilter: fp32, interleaved like the PCM
+    if (nchan == 1) {       // mono batch: channel 1 of the subband buffer stays silent (zeros)
+        const float *srcf = pcmf + (long long) s * nsamp;
+        for (int idx = hist + threadIdx.x; idx < count; idx += 512)
+            xs2[0][idx + (idx >> 5)] = pcmf ? srcf[n0 + idx] : (float) src[n0 + idx];
+    } else if (pcmf) {      // DC-blocked input from k_dcfilter: fp32, interleaved like the PCM
         const float2 *srcf = reinterpret_cast<const float2 *>(pcmf) + (long long) s * nsamp;
         for (int idx = hist + threadIdx.x; idx < count; idx += 512) {
             const float2 v = srcf[n0 + idx];
@@ -108,11 +112,12 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
             xs2[1][idx + (idx >> 5)] = (float) src[2 * n + 1];
         }
     }
-    for (int idx = threadIdx.x; idx < 2 * hist; idx += 512) {
+    for (int idx = threadIdx.x; idx < nchan * hist; idx += 512) {
         const int c = idx >= 480, i = idx - 480 * c;
         xs2[c][i + (i >> 5)] = ss->pcm_hist[c][i];
     }
     __syncthreads();
+    if (ch >= nchan) return;
     const float *xs = xs2[ch];
     const int gl = lt / 18, t = lt - gl * 18;
     if (gl >= ng) return;
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
 // After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
 // last 480 input samples into the stream state.
 __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const int16_t *__restrict__ pcm,
-                        long long nsamp, int NG, int SG, int S, const float *__restrict__ pcmf)
+                        long long nsamp, int NG, int SG, int S, const float *__restrict__ pcmf, int nchan)
 {
     const int sc = blockIdx.x;                  // s*2 + ch
     const int s = sc >> 1, ch = sc & 1;
@@ -632,11 +637,11 @@ __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const
     for (int e = threadIdx.x; e < 576; e += blockDim.x)
         for (int k = 0; k < 3; k++) base[k * 576 + e] = base[(NG + k) * 576 + e];
     HxStream *ss = st + s;
-    const int16_t *src = pcm + (long long) s * nsamp * 2 + ch;
-    for (int i = threadIdx.x; i < 480; i += blockDim.x) {
+    const int16_t *src = pcm + (long long) s * nsamp * nchan + ch;
+    for (int i = threadIdx.x; i < 480 && ch < nchan; i += blockDim.x) {
         long long n = nsamp - 480 + i;
         // fewer than 480 new samples never happens (a frame is 1152), so all come from this batch
-        ss->pcm_hist[ch][i] = pcmf ? pcmf[((long long) s * nsamp + n) * 2 + ch] : (float) src[2 * n];
+        ss->pcm_hist[ch][i] = pcmf ? pcmf[((long long) s * nsamp + n) * nchan + ch] : (float) src[nchan * n];
     }
     if (threadIdx.x == 0 && ch == 0) ss->frames_in += (int) (nsamp / 1152);
 }
@@ -646,18 +651,18 @@ __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const
 // evaluated in the reference's order, so it is sequential per channel: one lane per
 // (stream, channel) walks its samples; streams without the filter are converted to float only.
 __global__ void k_dcfilter(const int16_t *__restrict__ pcm, const float *__restrict__ pcm32, long long nsamp,
-                           HxStream *__restrict__ st, const HxParams *__restrict__ prm, float *__restrict__ pcmf, int S)
+                           HxStream *__restrict__ st, const HxParams *__restrict__ prm, float *__restrict__ pcmf, int S, int nchan)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= 2 * S) return;
-    const int s = u >> 1, ch = u & 1;
+    if (u >= nchan * S) return;
+    const int s = u / nchan, ch = u - s * nchan;
     HxStream *ss = st + s;
     const HxParams *p = prm + ss->cls;
-    const int16_t *src = pcm + (long long) s * nsamp * 2 + ch;
-    const float *srcf = pcm32 + (long long) s * nsamp * 2 + ch;
-    float *dst = pcmf + (long long) s * nsamp * 2 + ch;
+    const int16_t *src = pcm + (long long) s * nsamp * nchan + ch;
+    const float *srcf = pcm32 + (long long) s * nsamp * nchan + ch;
+    float *dst = pcmf + (long long) s * nsamp * nchan + ch;
     if (!p->filter_dc) {
-        for (long long n = 0; n < nsamp; n++) dst[2 * n] = pcm32 ? srcf[2 * n] : (float) src[2 * n];
+        for (long long n = 0; n < nsamp; n++) dst[nchan * n] = pcm32 ? srcf[nchan * n] : (float) src[nchan * n];
         return;
     }
     const float alpha = p->filter_alpha;
@@ -665,12 +670,12 @@ __global__ void k_dcfilter(const int16_t *__restrict__ pcm, const float *__restr
     for (long long n0 = 0; n0 < nsamp; n0 += 8) {      // nsamp is a multiple of 1152
         float x[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = pcm32 ? srcf[2 * (n0 + k)] : (float) src[2 * (n0 + k)];
+        for (int k = 0; k < 8; k++) x[k] = pcm32 ? srcf[nchan * (n0 + k)] : (float) src[nchan * (n0 + k)];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const float t = x[k] - d;
             d = d + alpha * t;
-            dst[2 * (n0 + k)] = t;
+            dst[nchan * (n0 + k)] = t;
         }
     }
     ss->dc[ch] = d;

@@ -316,11 +316,12 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     for (int i = 0; i < 8; i++) { int d = abs(ec.samprate - sr_all[i]); if (d < dmin) { dmin = d; k = i; } }
     if ((k >> 2) != 1) return 0;                    // MPEG-2 LSF rates: not on this path
     p->sr_index = k & 3;
-    if (ec.mode != 0 && ec.mode != 1) return 0;     // dual channel / mono: not on this path
+    if (ec.mode == 2) return 0;                     // dual channel (legacy allocator): not on this path
     p->h_mode = ec.mode;
+    p->nchan = (ec.mode == 3) ? 1 : 2;
     int mode_ext = (p->h_mode == 1) ? ec.nsbstereo / 4 - 1 : 0;
     mode_ext = MN(MX(mode_ext, 0), 3);
-    int bitrate = MX(ec.bitrate, 8) * 2;
+    int bitrate = MX(ec.bitrate, 8) * p->nchan;     // per-channel request; a mono frame carries one channel (setup.c:254-258)
     if (bitrate > 320) bitrate = 320;
     int br_index = 0;
     for (int i = 1; br_mpeg1_l3[i] >= 0; i++) if (br_mpeg1_l3[i] == bitrate) br_index = i;
@@ -345,10 +346,12 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     p->divisor = p->samprate;
     p->framebytes = 144000 * p->totbitrate / p->divisor;
     p->remainder = (144000 * p->totbitrate) % p->divisor;
-    p->side_bytes = 32;
+    p->side_bytes = (p->h_mode == 3) ? 17 : 32;
     p->main_framebytes = p->framebytes - 4 - p->side_bytes;
     p->sf_bit_max = 3 * (6 * 4 + 6 * 3);
-    p->AveTargetBits = ((8 * p->main_framebytes / 2) >> 1) - p->sf_bit_max;
+    p->AveTargetBits = 8 * p->main_framebytes / 2;          // bits per granule ...
+    if (p->h_mode != 3) p->AveTargetBits >>= 1;             // ... and per channel
+    p->AveTargetBits -= p->sf_bit_max;
 
     int nsb_user_flag = 0, u1 = 32, u2 = 32, freq_limit;
     if (ec.nsb_limit > 0) {
@@ -368,7 +371,7 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     } else {
         static const float factor[4] = {1.1f, 1.333f, 1.0f, 1.0f};
         float chan_bitrate = (float) p->totbitrate;
-        chan_bitrate = (float) (0.5 * chan_bitrate);
+        if (p->h_mode != 3) chan_bitrate = (float) (0.5 * chan_bitrate);
         chan_bitrate = factor[p->h_mode] * chan_bitrate;
         freq_limit = (int) (187.97 * chan_bitrate);
     }
@@ -401,21 +404,21 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
         for (int i = 1; i < 15; i++) {
             int mb = 144000 * br_mpeg1_l3[i] / p->samprate;
             p->vbr_framebytes[i] = mb;
-            p->vbr_main_framebytes[i] = mb - 4 - 32;
+            p->vbr_main_framebytes[i] = mb - 4 - p->side_bytes;
         }
         p->vbr_framebytes[15] = p->vbr_main_framebytes[15] = 9999999;
         p->vbr_pool_target = 256;
         int i;
         for (i = 14; i >= 2; i--) {
-            if (2 * ec.vbr_br_limit >= br_mpeg1_l3[i]) break;
+            if (p->nchan * ec.vbr_br_limit >= br_mpeg1_l3[i]) break;
             p->vbr_pool_target = (p->vbr_pool_target + 511) >> 1;
         }
         p->ivbr_max = i;
         p->ivbr_min = 1;
-        p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / 4) - p->sf_bit_max;
+        p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / (2 * p->nchan)) - p->sf_bit_max;
         p->initialMNR = MN(MX(10 * ec.vbr_mnr, 210), 1500);
     } else {
-        p->initialMNR = MN(MX(125 * (p->totbitrate / 2 - 32) / 8, 0), 1000);
+        p->initialMNR = MN(MX(125 * (p->totbitrate / p->nchan - 32) / 8, 0), 1000);
     }
     ec.vbr_delta_mnr = MX(MN(ec.vbr_delta_mnr, 50), -40);
     for (int i = 0; i < 21; i++) ec.mnr_adjust[i] = MX(MN(ec.mnr_adjust[i], 200), -200);
@@ -469,13 +472,13 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
 
     p->ec = ec;
     p->ec.mode = p->h_mode;
-    p->ec.bitrate = p->totbitrate / 2;
+    p->ec.bitrate = p->totbitrate / p->nchan;
     p->ec.samprate = p->samprate;
     p->ec.nsbstereo = 32;
     p->ec.freq_limit = ec.hf_flag ? ec.freq_limit : p->nsb_limit * (p->samprate / 64);
     p->ec.nsb_limit = p->nsb_limit;
     p->ec.layer = 3;
-    return 2 * 4 * 1152;
+    return p->nchan * 4 * 1152;
 }
 
 // Initial per-stream state (mp3enc.cpp:278-287,614-621,788-837; bitallo3.cpp:300-316)

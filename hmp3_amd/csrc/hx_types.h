@@ -38,6 +38,7 @@ struct HxParams {
     int nband, nsb, nsb_limit, nsb_ms0, nsb_ms1, band_limit, band_limit_stereo;
     int framebytes, remainder, divisor, main_framebytes, side_bytes, sf_bit_max, AveTargetBits;
     int ms_flag, hf_flag, vbr_flag, short_block_threshold, filter_dc;
+    int nchan;              // 1 = mono (mode 3), 2 = stereo / joint stereo
     float filter_alpha;
     int ivbr_min, ivbr_max, vbr_main_framebytes[16], vbr_framebytes[16], vbr_pool_target;
     int initialMNR, test1, taperNT[22];

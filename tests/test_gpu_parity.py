@@ -76,7 +76,8 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
 
 
 @pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc",
-                                  "cli_vbr50_s24_44k", "cli_cbr128_u8_44k", "cli_vbr50_s32_48k"])
+                                  "cli_vbr50_s24_44k", "cli_cbr128_u8_44k", "cli_vbr50_s32_48k",
+                                  "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
     reference CLI (tests/golden/cli_*.mp3, tools/make_golden_cli.py)"""
@@ -108,6 +109,33 @@ def test_packet_variant_matches_oracle(kw):
         want_bs, want_pk = o.encode_packet(pcm[f * 1152:(f + 1) * 1152])
         assert nin == 9216 and bs == want_bs and pk == want_pk, "frame %d" % f
     e.close()
+
+
+MONO = {
+    "mono_cbr64": dict(bitrate=64, mode=3),
+    "mono_vbr50": dict(mode=3),
+    "mono_cbr96_48k": dict(bitrate=96, mode=3, samprate=48000),
+    "mono_vbr100_hf_48k": dict(mode=3, vbr_mnr=100, hf_flag=3, samprate=48000, freq_limit=19000),
+    "mono_cbr48_32k_long_dc": dict(bitrate=48, mode=3, samprate=32000, short_block_threshold=99999, filter_select=1),
+}
+
+
+@pytest.mark.parametrize("name", list(MONO))
+def test_mono_batch_byte_identical_to_oracle(name):
+    """mode 3: one channel, 17-byte side info, encode_singleB budgets; block switching on by default"""
+    kw = MONO[name]
+    sr = kw.get("samprate", 44100)
+    S, F = 6, 40
+    pcm = np.stack([synth.stream_pcm(500 + i, F, sr=sr, bursts=True)[:, i & 1] for i in range(S)])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    got = b.encode_host(pcm[:, :25 * 1152])
+    got2 = b.encode_host(pcm[:, 25 * 1152:])
+    assert b.status() == 0
+    for s in range(S):
+        enc = O.OracleEncoder(O.default_control(**kw))
+        want = b"".join(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F))
+        assert got[s] + got2[s] == want, "stream %d" % s
+    b.close()
 
 
 def test_float_input_and_dc_filter_mixed_batch():

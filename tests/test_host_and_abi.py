@@ -16,7 +16,8 @@ TABLES = ["psy_w", "psy_cnt", "psy_off", "psy_nsum", "psy_npart", "win", "csa", 
           "look_gain", "look_34igain", "look_ix43", "look_log_cbwmb", "nBand_l", "startBand_l", "nsf", "taperNT",
           "head", "ec", "scalars"]
 CONFIGS = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000),
-           dict(samprate=32000, bitrate=64), dict(bitrate=96, mode=0), dict(bitrate=160), dict(vbr_mnr=120, quick=0)]
+           dict(samprate=32000, bitrate=64), dict(bitrate=96, mode=0), dict(bitrate=160), dict(vbr_mnr=120, quick=0),
+           dict(bitrate=64, mode=3), dict(mode=3, samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(bitrate=48, mode=3, samprate=32000)]
 
 
 def test_library_exports_every_declared_symbol():
@@ -55,7 +56,8 @@ def test_resolve_rejects_what_reference_rejects_and_out_of_scope():
     assert ok(bitrate=64) and ok() and ok(bitrate=48)
     assert not ok(bitrate=40)               # mp3enc.cpp:346-351
     assert not ok(bitrate=64, layer=2)      # mp3enc.cpp:388
-    assert not ok(bitrate=64, mode=3)       # mono: documented out of scope
+    assert ok(bitrate=64, mode=3)           # mono
+    assert not ok(bitrate=64, mode=2)       # dual channel: documented out of scope
     assert not ok(bitrate=32, samprate=22050)   # MPEG-2: documented out of scope
 
 

@@ -103,7 +103,8 @@ def test_init_rejections_follow_reference():
     assert not O.OracleEncoder(O.default_control(bitrate=40)).ok()
     assert not O.OracleEncoder(O.default_control(bitrate=64, layer=2)).ok()
     # outside this path's scope (documented): mono and MPEG-2 rates
-    assert not O.OracleEncoder(O.default_control(bitrate=64, mode=3)).ok()
+    assert O.OracleEncoder(O.default_control(bitrate=64, mode=3)).ok()      # mono is restated
+    assert not O.OracleEncoder(O.default_control(bitrate=64, mode=2)).ok()  # dual channel: out of scope
     assert not O.OracleEncoder(O.default_control(bitrate=32, samprate=22050)).ok()
     assert O.OracleEncoder(O.default_control(bitrate=64)).bytes_in == 9216
 

@@ -24,11 +24,24 @@ CASES = {
     "cli_vbr50_s24_44k": (904, 60007, 44100, 24, False, []),
     "cli_cbr128_u8_44k": (905, 50003, 44100, 8, False, ["-B64"]),
     "cli_vbr50_s32_48k": (906, 50003, 48000, 32, False, ["-V50"]),
+    # mono WAVs (mode 3): the left channel of the synthetic stream
+    "cli_mono_cbr64_s16_44k": (907, 90001, 44100, False, True, ["-B64"]),
+    "cli_mono_vbr60_f32_48k": (908, 60013, 48000, True, True, ["-V60"]),
 }
+MONO = {"cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k"}
 
 
 def write_wav(path, pcm_i16, sr, as_float):
     n = pcm_i16.shape[0]
+    if pcm_i16.ndim == 1:       # mono: 16-bit or float only
+        data = (pcm_i16.astype(np.float32) / 32768.0).astype("<f4").tobytes() if as_float is True else pcm_i16.astype("<i2").tobytes()
+        bps = 4 if as_float is True else 2
+        fmt = struct.pack("<HHIIHH", 3 if as_float is True else 1, 1, sr, sr * bps, bps, 8 * bps)
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE")
+            f.write(b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+            f.write(b"data" + struct.pack("<I", len(data)) + data)
+        return n
     if as_float is True:
         data = (pcm_i16.astype(np.float32) / 32768.0).astype("<f4").tobytes()
         fmt = struct.pack("<HHIIHH", 3, 2, sr, sr * 8, 8, 32)
@@ -56,7 +69,8 @@ def write_wav(path, pcm_i16, sr, as_float):
 def case_pcm(name):
     seed, nsamp, sr, as_float, bursts, flags = CASES[name]
     nfr = (nsamp + 1151) // 1152
-    return synth.stream_pcm(seed, nfr, sr=sr, rho=0.5, bursts=bursts)[:nsamp]
+    pcm = synth.stream_pcm(seed, nfr, sr=sr, rho=0.5, bursts=bursts)[:nsamp]
+    return pcm[:, 0].copy() if name in MONO else pcm
 
 
 if __name__ == "__main__":
