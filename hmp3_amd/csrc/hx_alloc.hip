@@ -421,10 +421,10 @@ __device__ void pow34_gzero(AllocLds &L, const AllocPrm *p, int nl0, int nl1, in
     // (the reference's vect_fmax compares them as integers too, pow34.c:156-186)
     // Chunks of three lines per lane, all loads (line, tables) ahead of the stores; lines past
     // nl store into the per-lane sink so the chunk stays one basic block.
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < 2; c++) {
         const int nl = c ? nl1 : nl0;
-#pragma unroll
+#pragma unroll 1
         for (int c3 = 0; c3 < 3; c3++) {
             if (192 * c3 >= nl) continue;
             float v[3];
@@ -458,10 +458,10 @@ __device__ void pow34_gzero(AllocLds &L, const AllocPrm *p, int nl0, int nl1, in
 __device__ void startup_lr(AllocLds &L, const AllocPrm *p)
 {
     const int mnr = L.MNR + 100;
-#pragma unroll
+#pragma unroll 1
     for (int ch = 0; ch < 2; ch++) {
         const int nl = p->nbmax3[ch];
-#pragma unroll
+#pragma unroll 1
         for (int c3 = 0; c3 < 3; c3++) {        // three lines per lane and chunk, loads first
             if (192 * c3 >= nl) continue;
             float x[3];
@@ -514,7 +514,7 @@ __device__ void startup_ms(AllocLds &L, const AllocPrm *p)
     const int nl = p->hf_flag ? L.startBand[22] : p->nbmax[0];     // lines that get the M/S butterfly
     // one pass over the lines: L/R energy terms, M/S butterfly (reference l3math.c:905-930, no
     // 1/sqrt(2)), M/S energy terms (kept in the x34 array, which is not live yet)
-#pragma unroll
+#pragma unroll 1
     for (int c3 = 0; c3 < 3; c3++) {            // three lines per lane and chunk, loads first
         if (192 * c3 >= nl) continue;
         float lv[3], rv[3];
@@ -889,10 +889,10 @@ __device__ void do_quant(AllocLds &L, const AllocPrm *p, int opt)
     SYNC();
     // three lines per lane and chunk: band -> igain -> rounding offset are dependent LDS reads,
     // the three chains overlap; stores (and the band maximum) come after all loads of the chunk
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < 2; c++) {
         const int nl = p->nbmax[c];
-#pragma unroll
+#pragma unroll 1
         for (int c3 = 0; c3 < 3; c3++) {
             if (192 * c3 >= nl) continue;
             int q[3], b[3];
