@@ -117,12 +117,13 @@ int main(int argc, char **argv)
         return 1;
     }
     if (ec.mode < 0) ec.mode = 0;
+    const int mono_convert = ec.mode == 3;      // -M3: encode one channel (tomp3.cpp:562-563)
     if (wi.channels == 1) ec.mode = 3;
-    else if (ec.mode == 3) { fprintf(stderr, "\n UNSUPPORTED: down-mixing a stereo file to mono (-M3) is not on the GPU path\n"); return 1; }
+    else if (ec.mode == 3) ec.mode = 1;
     ec.samprate = wi.rate;
 
     hx_enc *enc = hx_enc_create(0);
-    const int frame_in = enc ? hx_enc_MP3_audio_encode_init(enc, &ec, wi.bits, is_float, 0, 0) : 0;
+    const int frame_in = enc ? hx_enc_MP3_audio_encode_init(enc, &ec, wi.bits, is_float, 0, mono_convert) : 0;
     if (!frame_in) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
     FILE *out = strcmp(fout, "-") ? fopen(fout, "w+b") : stdout;
     if (!out) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE\n"); return 1; }

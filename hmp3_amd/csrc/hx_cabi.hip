@@ -373,6 +373,7 @@ struct hx_enc {
     hx_batch *b = nullptr;
     HxParams p;
     int src_bits = 0, src_float = 0;
+    int src_chan = 2;                   // channels of the caller's PCM (2 with mono_convert: down-mixed to one)
     std::vector<int16_t> pcm16;
     std::vector<unsigned char> outbuf;
     unsigned frames = 0, bytes = 0;
@@ -471,21 +472,25 @@ extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, i
                                             int mpeg_select, int mono_convert)
 {
     (void) mpeg_select;
-    if (mono_convert) { set_err("down-mixing to mono is not on the GPU path"); return 0; }
+    // mp3enc.cpp:2693-2700: the source is mono iff ec->mode == 3; mono_convert encodes one channel
+    HX_E_CONTROL ec2 = *ec;
+    const int src_chan = (ec->mode == 3) ? 1 : 2;
+    if (mono_convert) ec2.mode = 3;
     if (!(source_bits == 8 || source_bits == 16 || source_bits == 24 || source_bits == 32)) { set_err("8, 16, 24 or 32-bit sources only"); return 0; }
     if (source_is_float && source_bits != 32) { set_err("float sources are 32-bit"); return 0; }
     if (ec->samprate != 32000 && ec->samprate != 44100 && ec->samprate != 48000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
-    int r = hx_enc_L3_audio_encode_init(e, ec);
+    int r = hx_enc_L3_audio_encode_init(e, &ec2);
     if (!r) return 0;
     e->src_bits = source_bits;
     e->src_float = source_is_float;
-    return 1152 * e->p.nchan * (source_bits / 8);
+    e->src_chan = src_chan;
+    return 1152 * src_chan * (source_bits / 8);
 }
 
 extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out)
 {
-    const int ns = 1152 * e->p.nchan;       // samples per call
-    if (e->src_bits == 16) return encode_one(e, pcm, 0, bs_out, 2 * ns);
+    const int ns = 1152 * e->src_chan;      // samples per call
+    if (e->src_bits == 16 && e->src_chan == e->p.nchan) return encode_one(e, pcm, 0, bs_out, 2 * ns);
     // every other sample format becomes fp32 at int16 scale exactly as Csrc::sr_convert does it
     // (srcc.cpp:804-836), little-endian input
     std::vector<float> t(ns);
@@ -501,9 +506,14 @@ extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm
             const int s = (int) (((unsigned) b[2] << 24) | ((unsigned) b[1] << 16) | ((unsigned) b[0] << 8)) >> 8;
             t[i] = (float) ((float) s / 256.0f);
         }
+    } else if (e->src_bits == 16) {
+        const int16_t *s = (const int16_t *) pcm;
+        for (int i = 0; i < ns; i++) t[i] = (float) s[i];
     } else {
         for (int i = 0; i < ns; i++) t[i] = (((float) pcm[i]) - 128.0f) * (256.0f);
     }
+    if (e->src_chan == 2 && e->p.nchan == 1)        // stereo source, mono stream (srccf.cpp:458-468)
+        for (int i = 0; i < 1152; i++) t[i] = (float) ((t[2 * i] + t[2 * i + 1]) * 0.5);
     HX_IN_OUT x = hx_enc_L3_audio_encode(e, t.data(), bs_out);
     x.in_bytes = ns * (e->src_bits / 8);
     return x;

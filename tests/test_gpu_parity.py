@@ -77,7 +77,8 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
 
 @pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc",
                                   "cli_vbr50_s24_44k", "cli_cbr128_u8_44k", "cli_vbr50_s32_48k",
-                                  "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k"])
+                                  "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k",
+                                  "cli_downmix_vbr50_s16_44k", "cli_downmix_cbr64_s24_48k"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
     reference CLI (tests/golden/cli_*.mp3, tools/make_golden_cli.py)"""

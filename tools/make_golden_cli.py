@@ -27,6 +27,9 @@ CASES = {
     # mono WAVs (mode 3): the left channel of the synthetic stream
     "cli_mono_cbr64_s16_44k": (907, 90001, 44100, False, True, ["-B64"]),
     "cli_mono_vbr60_f32_48k": (908, 60013, 48000, True, True, ["-V60"]),
+    # stereo file encoded as mono (-M3: down-mix)
+    "cli_downmix_vbr50_s16_44k": (909, 60001, 44100, False, True, ["-M3"]),
+    "cli_downmix_cbr64_s24_48k": (910, 50021, 48000, 24, False, ["-M3", "-B64"]),
 }
 MONO = {"cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k"}
 
