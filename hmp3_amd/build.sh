@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="$HX_EXTRA --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 ${HX_OPT:--O3} $HX_EXTRA -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
 $HIPCC $FLAGS -c hx_front.hip -o hx_front.o
 $HIPCC $FLAGS -c hx_alloc.hip -o hx_alloc.o
 $HIPCC $FLAGS -c hx_cabi.hip -o hx_cabi.o

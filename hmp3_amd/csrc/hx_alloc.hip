@@ -113,6 +113,9 @@ struct alignas(16) AllocLds {
 #define PROF_CNT(id) do { } while (0)
 #define PROF_ACC(id) do { } while (0)
 #endif
+// Rarely taken paths are kept out of line, away from the hot code: the kernel's instructions do not fit
+// the instruction cache that the waves of a CU share (DESIGN.md, K6 in detail).
+#define HX_COLD __attribute__((noinline, cold))
 #define LANE ((int) threadIdx.x)
 // The workgroup is a single wavefront, and a wave's LDS operations execute in issue order, so an
 // LDS hand-over between lanes only needs the compiler to keep the accesses in program order.
