@@ -269,6 +269,41 @@ def test_edge_inputs_silence_fullscale_single_stream():
     b.close()
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("cbr96_lowrate", dict(bitrate=48)),                       # starved: decrease_bits / limit_bits / part2_3 cap
+    ("cbr320_highrate", dict(bitrate=160)),                    # rich: increase_bits, large quantised values, linbits
+    ("vbr150_hf", dict(vbr_mnr=150, hf_flag=3, freq_limit=22000)),
+    ("vbr0", dict(vbr_mnr=0)),
+    ("cbr128_lr", dict(bitrate=64, mode=0)),
+])
+def test_stress_signals_rare_paths(name, kw):
+    """signals built to reach the allocator's rare branches: full-scale white noise (bit starvation, the
+    4021-bit part2_3 cap), a full-scale low tone (quantised values beyond the 256-entry x^(4/3) table ->
+    pow() path, escape codes), Nyquist alternation, DC offset, clicks in silence, hard-panned and
+    anti-phase channels, and a stream that changes character every few frames"""
+    F = 36
+    n = F * 1152
+    rng = np.random.default_rng(77)
+    t = np.arange(n)
+    noise = rng.integers(-32768, 32768, (n, 2)).astype(np.int16)
+    tone = np.round(32767 * np.sin(2 * np.pi * 110.0 * t / 44100.0)).astype(np.int16)
+    lowtone = np.stack([tone, tone], axis=1)
+    nyq = np.stack([np.where(t % 2 == 0, 32767, -32768), np.where(t % 2 == 0, -20000, 20000)], axis=1).astype(np.int16)
+    dc = np.stack([np.full(n, 12000), np.full(n, -32768)], axis=1).astype(np.int16)
+    clicks = np.zeros((n, 2), dtype=np.int16); clicks[::4001, 0] = 32767; clicks[1000::5003, 1] = -32768
+    panned = np.stack([tone, np.zeros(n, dtype=np.int16)], axis=1)
+    anti = np.stack([noise[:, 0] // 2, -(noise[:, 0] // 2)], axis=1).astype(np.int16)
+    seg = np.concatenate([x[i * 4608:(i + 1) * 4608] for i, x in enumerate([noise, lowtone, clicks, nyq, anti, dc, panned, noise, lowtone] * 2)])[:n]
+    pcm = np.stack([noise, lowtone, nyq, dc, clicks, panned, anti, seg])
+    S = pcm.shape[0]
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    for s in range(S):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), "%s: stress stream %d" % (name, s)
+    b.close()
+
+
 def test_cmp3enc_surface_single_stream():
     """the CMp3Enc-compatible entry points: init return values, per-frame encode, getters"""
     a = api()

@@ -53,6 +53,26 @@ def test_block_switching_streams_byte_identical(name, kw, sr, rho, nfr):
     assert len(a) > 0 and a == b
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=48), dict(bitrate=160), dict(vbr_mnr=150, hf_flag=3, freq_limit=22000), dict(vbr_mnr=0),
+                                dict(bitrate=64, mode=0)], ids=["cbr96", "cbr320", "vbr150hf", "vbr0", "cbr128lr"])
+def test_stress_signals_byte_identical(kw):
+    """the rare-branch signals of tests/test_gpu_parity.py::test_stress_signals_rare_paths, oracle vs reference"""
+    F = 36
+    n = F * 1152
+    rng = np.random.default_rng(77)
+    t = np.arange(n)
+    noise = rng.integers(-32768, 32768, (n, 2)).astype(np.int16)
+    tone = np.round(32767 * np.sin(2 * np.pi * 110.0 * t / 44100.0)).astype(np.int16)
+    lowtone = np.stack([tone, tone], axis=1)
+    nyq = np.stack([np.where(t % 2 == 0, 32767, -32768), np.where(t % 2 == 0, -20000, 20000)], axis=1).astype(np.int16)
+    clicks = np.zeros((n, 2), dtype=np.int16); clicks[::4001, 0] = 32767; clicks[1000::5003, 1] = -32768
+    anti = np.stack([noise[:, 0] // 2, -(noise[:, 0] // 2)], axis=1).astype(np.int16)
+    for pcm in (noise, lowtone, nyq, clicks, anti):
+        a = O.encode_stream(O.RefEncoder(O.default_control(**kw)), pcm)
+        b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+        assert len(a) > 0 and a == b
+
+
 MONO_CASES = [
     ("mono_cbr64", dict(bitrate=64, mode=3), 44100),
     ("mono_vbr50", dict(mode=3), 44100),
