@@ -38,7 +38,7 @@ class IntPair(C.Structure):
 EXPORTS = [
     "hx_last_error", "hx_device_count", "hx_default_control",
     "hx_enc_create", "hx_enc_destroy", "hx_enc_L3_audio_encode_init", "hx_enc_L3_audio_encode",
-    "hx_enc_MP3_audio_encode_init", "hx_enc_MP3_audio_encode", "hx_enc_L3_audio_encode_Packet", "hx_enc_MP3_audio_encode_Packet", "hx_batch_packet_buffers", "hx_enc_get_bitrate",
+    "hx_enc_MP3_audio_encode_init", "hx_enc_MP3_audio_encode", "hx_enc_L3_audio_encode_Packet", "hx_enc_MP3_audio_encode_Packet", "hx_batch_packet_buffers", "hx_batch_frame_stats_buffer", "hx_batch_encode_f32_host_stats", "hx_control_info", "hx_enc_get_bitrate",
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",

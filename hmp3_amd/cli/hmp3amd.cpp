@@ -1,9 +1,13 @@
-// hmp3amd - file front end over libhmp3amd: `hmp3amd <input.wav|-> <output.mp3|-> [flags]`.
-// Same command line, encode loop and output file as the reference CLI (SURVEY §8 f1/f2;
-// reference test/tomp3.cpp:336-602 main, :645-1088 ff_encode): Xing/Info tag frame first, audio
-// frames, four frames of silence behind the input, drain until every submitted frame is out, then
-// the tag is completed in place.  Accepted here: RIFF/WAVE, mono or stereo, 8/16/24/32-bit PCM or 32-bit float,
+// hmp3amd - file front end over libhmp3amd.
+//   hmp3amd <input.wav|-> <output.mp3|-> [flags]                 one file, frame by frame (hx_enc_* API)
+//   hmp3amd -batch in1.wav out1.mp3 in2.wav out2.mp3 ... [flags]  many files at once (hx_batch_* API)
+// Same flags, encode loop and output files as the reference CLI (reference
+// test/tomp3.cpp:336-602 main, :645-1088 ff_encode): Xing/Info tag frame first, audio frames, four
+// frames of silence behind the input, drain until every submitted frame is out, then the tag is
+// completed in place.  Accepted: RIFF/WAVE, mono or stereo, 8/16/24/32-bit PCM or 32-bit float,
 // 32 / 44.1 / 48 kHz (what the GPU path encodes); everything else fails like an unsupported file.
+// Batch mode encodes all files as one batch of streams (same channel count, same flags) and
+// reproduces per file exactly what the single-file loop writes.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +20,7 @@
 namespace {
 
 struct WavInfo { int channels = 0, rate = 0, bits = 0, type = 0; uint64_t data_bytes = 0; };
+struct Options { HX_E_CONTROL ec; int xing_flag = 3 | 0x40, ignore_length = 0; };
 
 unsigned rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned) p[3] << 24); }
 unsigned rd16(const unsigned char *p) { return p[0] | (p[1] << 8); }
@@ -58,32 +63,257 @@ bool wav_header(FILE *f, WavInfo *w)
 void usage()
 {
     fprintf(stderr,
-            "\n hmp3amd <input.wav|-> <output.mp3|-> [-Bn] [-Vn] [-Mn] [-Fn] [-HFn] [-SBTn] [-Sn] [-Xn] [-Cn] [-On] [-Ln] [-Tn] [-TXn] [-IL]"
+            "\n hmp3amd <input.wav|-> <output.mp3|-> [flags]"
+            "\n hmp3amd -batch in1.wav out1.mp3 in2.wav out2.mp3 ... [flags]"
             "\n   -Bn  kbps per channel (CBR)      -Vn  VBR quality 0..150 (default 50)"
-            "\n   -Mn  0 stereo, 1 joint stereo    -Fn  low-pass Hz      -HFn high-frequency mode"
+            "\n   -Mn  0 stereo, 1 joint stereo, 3 mono      -Fn  low-pass Hz      -HFn high-frequency mode"
             "\n   -SBTn short-block threshold      -S1  DC blocker       -Xn  0 no tag, 1 Xing, 2/3 + TOC, default + info"
-            "\n   -IL  ignore the length field of the WAV header\n");
+            "\n   -Cn -On copyright / original bits   -Ln VBR bitrate cap   -Tn -TXn tuning   -IL ignore the WAV length field\n");
+}
+
+// one input file, read and checked
+struct Input {
+    WavInfo wi;
+    std::vector<unsigned char> data;    // the audio bytes followed by four frames of zero bytes
+    uint64_t audio_bytes = 0;
+    int frame_in = 0, mono_convert = 0, is_float = 0;
+    HX_E_CONTROL ec;                    // as given to the encoder
+    HX_E_CONTROL ec_used;               // as reported back (settings in use)
+    HX_MPEG_HEAD head;
+};
+
+bool load_input(const char *path, const Options &opt, Input *in)
+{
+    FILE *f = strcmp(path, "-") ? fopen(path, "rb") : stdin;
+    if (!f) { fprintf(stderr, "\n CANNOT_OPEN_INPUT_FILE %s\n", path); return false; }
+    const int ignore_length = opt.ignore_length || f == stdin;
+    if (!wav_header(f, &in->wi)) { fprintf(stderr, "\n UNRECOGNIZED PCM FILE TYPE\n"); return false; }
+    const WavInfo &wi = in->wi;
+    const uint64_t indatasize = ignore_length ? UINT64_MAX : wi.data_bytes;
+    if (indatasize == 0) { fprintf(stderr, "\n INPUT FILE CONTAINS NO AUDIO\n"); return false; }
+    fprintf(stderr, "\n pcm file:  channels = %d  bits = %d,  rate = %d  type = %d", wi.channels, wi.bits, wi.rate, wi.type);
+    in->is_float = wi.type == 3;
+    if ((wi.channels != 1 && wi.channels != 2) ||
+        !((wi.type == 1 && (wi.bits == 8 || wi.bits == 16 || wi.bits == 24 || wi.bits == 32)) || (in->is_float && wi.bits == 32)) ||
+        (wi.rate != 32000 && wi.rate != 44100 && wi.rate != 48000)) {
+        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes mono or stereo 8/16/24/32-bit PCM or 32-bit float input at 32 / 44.1 / 48 kHz.\n");
+        return false;
+    }
+    in->ec = opt.ec;
+    if (in->ec.mode < 0) in->ec.mode = 0;
+    in->mono_convert = in->ec.mode == 3;        // -M3: encode one channel (tomp3.cpp:562-563)
+    if (wi.channels == 1) in->ec.mode = 3;
+    else if (in->ec.mode == 3) in->ec.mode = 1;
+    in->ec.samprate = wi.rate;
+    in->frame_in = 1152 * wi.channels * (wi.bits / 8);
+    // The reference refills a 256-frame buffer and appends the silence when it meets the end of the
+    // data; feeding whole frames of (data ++ 4 frames of zero bytes) is the same sequence of calls.
+    std::vector<unsigned char> chunk(1 << 20);
+    while (in->data.size() < indatasize) {
+        size_t want = chunk.size();
+        if (in->data.size() + want > indatasize) want = (size_t) (indatasize - in->data.size());
+        const size_t got = fread(chunk.data(), 1, want, f);
+        in->data.insert(in->data.end(), chunk.begin(), chunk.begin() + got);
+        if (got < want) break;
+    }
+    in->audio_bytes = in->data.size();
+    in->data.resize(in->data.size() + 4 * (size_t) in->frame_in, 0);
+    if (f != stdin) fclose(f);
+    return true;
+}
+
+// the tag frame, its running seek table and the MusicCRC of one output file (tomp3.cpp:871-896, :976-984, :1055-1072)
+struct Tagger {
+    hx_xing *xg = hx_xing_create();
+    std::vector<unsigned char> tag = std::vector<unsigned char>(2048, 0);
+    int head_flags = 0, head_bytes = 0, vbr_scale = -1, toc_counter = 0;
+    unsigned crc = 0;
+    ~Tagger() { hx_xing_destroy(xg); }
+    void begin(const Input &in, int xing_flag)
+    {
+        if (xing_flag) head_flags = 1 | 2 | 8;
+        if (xing_flag & 2) head_flags |= 4 | 0x40;
+        if (!xing_flag) return;
+        if (in.ec_used.vbr_flag) vbr_scale = in.ec_used.vbr_mnr;
+        head_bytes = hx_xing_header(xg, in.ec_used.samprate, in.head.mode, in.ec_used.cr_bit, in.ec_used.original, head_flags, 0, 0,
+                                    vbr_scale, nullptr, tag.data(), nullptr, nullptr, in.ec_used.bitrate * in.wi.channels);
+    }
+    void after_call(unsigned frames_out, unsigned bytes_out)    // once per input frame of the main loop
+    {
+        if ((head_flags & 4) && --toc_counter <= 0) toc_counter = hx_xing_toc(xg, (int) frames_out + 1, (int) bytes_out + head_bytes);
+    }
+    void bytes(const unsigned char *p, int n) { crc = hx_xing_update_crc((unsigned short) crc, p, n); }
+    void finish(const Input &in, unsigned frames, uint64_t out_bytes)
+    {
+        const uint64_t samples_audio = in.audio_bytes / (uint64_t) (in.wi.channels * (in.wi.bits / 8));
+        hx_xing_update_info(xg, frames, (int) out_bytes, vbr_scale, nullptr, tag.data(), nullptr, nullptr, samples_audio,
+                            (unsigned) out_bytes, (unsigned) in.ec_used.freq_limit, (unsigned) in.wi.rate, (unsigned) in.ec_used.samprate,
+                            (unsigned short) crc);
+    }
+};
+
+int encode_one_file(const char *fin, const char *fout, const Options &opt)
+{
+    Input in;
+    if (!load_input(fin, opt, &in)) return 1;
+    hx_enc *enc = hx_enc_create(0);
+    const int frame_in = enc ? hx_enc_MP3_audio_encode_init(enc, &in.ec, in.wi.bits, in.is_float, 0, in.mono_convert) : 0;
+    if (!frame_in) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
+    FILE *out = strcmp(fout, "-") ? fopen(fout, "w+b") : stdout;
+    if (!out) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE\n"); return 1; }
+    char info[128];
+    hx_enc_info_string(enc, info);
+    fprintf(stderr, "\n %s\n", info);
+    hx_enc_info_ec(enc, &in.ec_used);       // the settings actually in use
+    hx_enc_info_head(enc, &in.head);
+    Tagger tg;
+    tg.begin(in, opt.xing_flag);
+    uint64_t out_bytes = tg.head_bytes;
+    if (tg.head_bytes && fwrite(tg.tag.data(), 1, tg.head_bytes, out) != (size_t) tg.head_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); return 1; }
+
+    std::vector<unsigned char> bs(128 * 1024), zero(frame_in, 0);
+    unsigned frames_expected = 0;
+    auto emit = [&](const HX_IN_OUT &x) {
+        if (x.out_bytes && fwrite(bs.data(), 1, x.out_bytes, out) != (size_t) x.out_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); exit(1); }
+        tg.bytes(bs.data(), x.out_bytes);
+        out_bytes += x.out_bytes;
+    };
+    for (size_t off = 0; off + frame_in <= in.data.size(); off += frame_in) {      // tomp3.cpp:906-1003
+        emit(hx_enc_MP3_audio_encode(enc, in.data.data() + off, bs.data()));
+        frames_expected++;
+        const HX_INT_PAIR fb = hx_enc_get_frames_bytes(enc);
+        tg.after_call((unsigned) fb.a, (unsigned) fb.b);
+    }
+    while (hx_enc_get_frames(enc) < frames_expected)                                // drain, tomp3.cpp:1020-1036
+        emit(hx_enc_MP3_audio_encode(enc, zero.data(), bs.data()));
+    const unsigned frames = hx_enc_get_frames(enc);
+    if (opt.xing_flag) {
+        tg.finish(in, frames, out_bytes);
+        if (out == stdout || fseek(out, 0, SEEK_SET) != 0) fprintf(stderr, "\n OUTPUT IS NOT SEEKABLE: TAG FRAME LEFT WITHOUT TOTALS");
+        else fwrite(tg.tag.data(), 1, tg.head_bytes, out);
+    }
+    fprintf(stderr, "\n %u frames, %llu bytes, %.2f kbps\n", frames, (unsigned long long) out_bytes, hx_enc_get_bitrate_float(enc));
+    if (out != stdout) fclose(out);
+    hx_enc_destroy(enc);
+    return frames == 0 ? 1 : 0;
+}
+
+// samples of one input frame as fp32 at int16 scale, the way Csrc::sr_convert / src_filter_to_mono_case0
+// produce them (srcc.cpp:804-836, srccf.cpp:458-468)
+void frame_to_float(const Input &in, const unsigned char *src, float *dst)
+{
+    const int ns = 1152 * in.wi.channels;
+    if (in.wi.bits == 32 && in.is_float) { const float *f = (const float *) src; for (int i = 0; i < ns; i++) dst[i] = f[i] * 32768.0f; }
+    else if (in.wi.bits == 32) { const int *s = (const int *) src; for (int i = 0; i < ns; i++) dst[i] = (float) (s[i] / 65536.0f); }
+    else if (in.wi.bits == 24)
+        for (int i = 0; i < ns; i++) {
+            const unsigned char *b = src + 3 * i;
+            const int s = (int) (((unsigned) b[2] << 24) | ((unsigned) b[1] << 16) | ((unsigned) b[0] << 8)) >> 8;
+            dst[i] = (float) ((float) s / 256.0f);
+        }
+    else if (in.wi.bits == 16) { const int16_t *s = (const int16_t *) src; for (int i = 0; i < ns; i++) dst[i] = (float) s[i]; }
+    else for (int i = 0; i < ns; i++) dst[i] = (((float) src[i]) - 128.0f) * (256.0f);
+    if (in.wi.channels == 2 && in.mono_convert)
+        for (int i = 0; i < 1152; i++) dst[i] = (float) ((dst[2 * i] + dst[2 * i + 1]) * 0.5);
+}
+
+int encode_batch(const std::vector<const char *> &files, const Options &opt)
+{
+    const int S = (int) files.size() / 2;
+    std::vector<Input> in(S);
+    std::vector<HX_E_CONTROL> ctl(S);
+    int nch = 0;
+    size_t max_calls = 0;
+    for (int i = 0; i < S; i++) {
+        if (!load_input(files[2 * i], opt, &in[i])) return 1;
+        HX_E_CONTROL ec = in[i].ec;
+        if (in[i].mono_convert) ec.mode = 3;
+        const int c = ec.mode == 3 ? 1 : 2;
+        if (nch && c != nch) { fprintf(stderr, "\n -batch needs files that all encode to the same channel count\n"); return 1; }
+        nch = c;
+        if (!hx_control_info(&ec, &in[i].ec_used, &in[i].head)) { fprintf(stderr, "\n ENCODER INIT FAIL (%s)\n", files[2 * i]); return 1; }
+        ctl[i] = ec;
+        const size_t calls = in[i].data.size() / in[i].frame_in;
+        if (calls > max_calls) max_calls = calls;
+    }
+    const int CH = 96;                                  // frames per batched call
+    const size_t total = max_calls + 32;                // room for the drain frames (a reservoir never spans that many)
+    hx_batch *b = hx_batch_create(0, S, ctl.data(), 0, CH);
+    if (!b) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
+    const long long stride = hx_batch_out_stride(b, CH);
+    std::vector<float> pcm((size_t) S * CH * 1152 * nch), tmp(2304);
+    const std::vector<unsigned char> zero_frame(2304 * 4, 0);
+    std::vector<unsigned char> out((size_t) S * stride);
+    std::vector<int> nb(S), stats((size_t) S * CH * 2);
+    std::vector<std::vector<unsigned char>> stream(S);
+    std::vector<std::vector<unsigned>> fr(S), by(S);    // per input frame: frames / bytes out so far
+    for (size_t c0 = 0; c0 < total; c0 += CH) {
+        for (int i = 0; i < S; i++) {
+            const size_t calls = in[i].data.size() / in[i].frame_in;
+            for (int k = 0; k < CH; k++) {
+                // past the end the single-file loop feeds frames of zero BYTES: silence, except for
+                // 8-bit unsigned input where a zero byte is full-scale negative
+                if (c0 + k < calls) frame_to_float(in[i], in[i].data.data() + (c0 + k) * in[i].frame_in, tmp.data());
+                else frame_to_float(in[i], zero_frame.data(), tmp.data());
+                memcpy(&pcm[((size_t) i * CH + k) * 1152 * nch], tmp.data(), sizeof(float) * 1152 * nch);
+            }
+        }
+        if (hx_batch_encode_f32_host_stats(b, pcm.data(), CH, out.data(), stride, nb.data(), stats.data()) != 0) {
+            fprintf(stderr, "\n ENCODE FAIL: %s\n", hx_last_error());
+            return 1;
+        }
+        for (int i = 0; i < S; i++) {
+            stream[i].insert(stream[i].end(), out.begin() + (size_t) i * stride, out.begin() + (size_t) i * stride + nb[i]);
+            for (int k = 0; k < CH; k++) { fr[i].push_back((unsigned) stats[((size_t) i * CH + k) * 2]); by[i].push_back((unsigned) stats[((size_t) i * CH + k) * 2 + 1]); }
+        }
+    }
+    if (hx_batch_status(b) != 0) fprintf(stderr, "\n WARNING: kernel status %d\n", hx_batch_status(b));
+    hx_batch_destroy(b);
+    // per file: what the single-file loop would have written
+    int rc = 0;
+    for (int i = 0; i < S; i++) {
+        const size_t calls = in[i].data.size() / in[i].frame_in;
+        Tagger tg;
+        tg.begin(in[i], opt.xing_flag);
+        for (size_t u = 0; u < calls; u++) tg.after_call(fr[i][u], by[i][u]);
+        size_t u = calls;                               // drain calls: while (get_frames() < frames_expected) encode silence
+        while (u < fr[i].size() && fr[i][u - 1] < calls) u++;
+        if (fr[i][u - 1] < calls) { fprintf(stderr, "\n %s: drain did not complete\n", files[2 * i]); rc = 1; }
+        const unsigned frames = fr[i][u - 1], nbytes = by[i][u - 1];
+        tg.bytes(stream[i].data(), (int) nbytes);
+        const uint64_t out_bytes = (uint64_t) tg.head_bytes + nbytes;
+        if (opt.xing_flag) tg.finish(in[i], frames, out_bytes);
+        FILE *o = fopen(files[2 * i + 1], "wb");
+        if (!o) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE %s\n", files[2 * i + 1]); rc = 1; continue; }
+        fwrite(tg.tag.data(), 1, tg.head_bytes, o);
+        fwrite(stream[i].data(), 1, nbytes, o);
+        fclose(o);
+        fprintf(stderr, "\n %s: %u frames, %llu bytes", files[2 * i + 1], frames, (unsigned long long) out_bytes);
+    }
+    fprintf(stderr, "\n");
+    return rc;
 }
 
 }  // namespace
 
 int main(int argc, char **argv)
 {
-    HX_E_CONTROL ec;
-    hx_default_control(&ec);        // the reference CLI's defaults (tomp3.cpp:357-384)
-    ec.bitrate = -1;
-    int xing_flag = 3 | 0x40, ignore_length = 0;
-    const char *fin = nullptr, *fout = nullptr;
-    int k = 0;
+    Options opt;
+    hx_default_control(&opt.ec);        // the reference CLI's defaults (tomp3.cpp:357-384)
+    opt.ec.bitrate = -1;
+    std::vector<const char *> files;
+    bool batch = false;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
-        if (a[0] != '-' || a[1] == '\0') { if (k == 0) fin = a; if (k == 1) fout = a; k++; continue; }
+        if (a[0] != '-' || a[1] == '\0') { files.push_back(a); continue; }
+        if (!strcmp(a, "-batch")) { batch = true; continue; }
+        HX_E_CONTROL &ec = opt.ec;
         const char c = (char) (a[1] | 0x20), c2 = (char) (a[2] | 0x20);
         switch (c) {
         case 'h': if (c2 == 'f') ec.hf_flag = 1 | atoi(a + 3); else { usage(); return 0; } break;
         case 'q': ec.quick = atoi(a + 2); break;
         case 'u': ec.cpu_select = atoi(a + 2); break;
-        case 'x': xing_flag = atoi(a + 2); if (xing_flag == 2) xing_flag = 3; break;
+        case 'x': opt.xing_flag = atoi(a + 2); if (opt.xing_flag == 2) opt.xing_flag = 3; break;
         case 'b': ec.bitrate = atoi(a + 2); break;
         case 'c': ec.cr_bit = atoi(a + 2); break;
         case 'o': ec.original = atoi(a + 2); break;
@@ -92,118 +322,18 @@ int main(int argc, char **argv)
         case 's': if (c2 == 'b' && (a[3] | 0x20) == 't') ec.short_block_threshold = atoi(a + 4); else ec.filter_select = atoi(a + 2); break;
         case 'f': ec.freq_limit = atoi(a + 2); break;
         case 't': if (c2 == 'x') ec.test1 = atoi(a + 3); else ec.vbr_delta_mnr = atoi(a + 2); break;
-        case 'i': if (c2 == 'l') ignore_length = 1; else ec.chan_add_f0 = atoi(a + 2); break;
+        case 'i': if (c2 == 'l') opt.ignore_length = 1; else ec.chan_add_f0 = atoi(a + 2); break;
         case 'j': ec.chan_add_f1 = atoi(a + 2); break;
         case 'v': ec.vbr_flag = 1; ec.vbr_mnr = atoi(a + 2); break;
         case 'l': ec.vbr_br_limit = atoi(a + 2); break;
         default: break;             // -D -EC -P -Z -A -W: display / reserved switches, no effect on the stream
         }
     }
-    if (!fin || !fout) { usage(); return 1; }
-    ec.vbr_flag = ec.bitrate < 0 ? 1 : 0;
-
-    FILE *in = strcmp(fin, "-") ? fopen(fin, "rb") : stdin;
-    if (!in) { fprintf(stderr, "\n CANNOT_OPEN_INPUT_FILE\n"); return 1; }
-    if (in == stdin) ignore_length = 1;
-    WavInfo wi;
-    if (!wav_header(in, &wi)) { fprintf(stderr, "\n UNRECOGNIZED PCM FILE TYPE\n"); return 1; }
-    uint64_t indatasize = ignore_length ? UINT64_MAX : wi.data_bytes;
-    if (indatasize == 0) { fprintf(stderr, "\n INPUT FILE CONTAINS NO AUDIO\n"); return 1; }
-    fprintf(stderr, "\n pcm file:  channels = %d  bits = %d,  rate = %d  type = %d", wi.channels, wi.bits, wi.rate, wi.type);
-    const bool is_float = wi.type == 3;
-    if ((wi.channels != 1 && wi.channels != 2) || !((wi.type == 1 && (wi.bits == 8 || wi.bits == 16 || wi.bits == 24 || wi.bits == 32)) || (is_float && wi.bits == 32)) ||
-        (wi.rate != 32000 && wi.rate != 44100 && wi.rate != 48000)) {
-        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes mono or stereo 8/16/24/32-bit PCM or 32-bit float input at 32 / 44.1 / 48 kHz.\n");
-        return 1;
+    opt.ec.vbr_flag = opt.ec.bitrate < 0 ? 1 : 0;
+    if (batch) {
+        if (files.empty() || (files.size() & 1)) { usage(); return 1; }
+        return encode_batch(files, opt);
     }
-    if (ec.mode < 0) ec.mode = 0;
-    const int mono_convert = ec.mode == 3;      // -M3: encode one channel (tomp3.cpp:562-563)
-    if (wi.channels == 1) ec.mode = 3;
-    else if (ec.mode == 3) ec.mode = 1;
-    ec.samprate = wi.rate;
-
-    hx_enc *enc = hx_enc_create(0);
-    const int frame_in = enc ? hx_enc_MP3_audio_encode_init(enc, &ec, wi.bits, is_float, 0, mono_convert) : 0;
-    if (!frame_in) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
-    FILE *out = strcmp(fout, "-") ? fopen(fout, "w+b") : stdout;
-    if (!out) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE\n"); return 1; }
-    char info[128];
-    hx_enc_info_string(enc, info);
-    fprintf(stderr, "\n %s\n", info);
-    hx_enc_info_ec(enc, &ec);       // the settings actually in use
-
-    // ---- tag frame first (tomp3.cpp:871-896) ----
-    int head_flags = 0, head_bytes = 0, vbr_scale = -1;
-    if (xing_flag) head_flags = 1 | 2 | 8;
-    if (xing_flag & 2) head_flags |= 4 | 0x40;
-    hx_xing *xg = hx_xing_create();
-    std::vector<unsigned char> tag(2048, 0);
-    uint64_t out_bytes = 0;
-    if (xing_flag) {
-        HX_MPEG_HEAD head;
-        hx_enc_info_head(enc, &head);
-        if (ec.vbr_flag) vbr_scale = ec.vbr_mnr;
-        head_bytes = hx_xing_header(xg, ec.samprate, head.mode, ec.cr_bit, ec.original, head_flags, 0, 0, vbr_scale, nullptr,
-                                    tag.data(), nullptr, nullptr, ec.bitrate * wi.channels);
-        if (fwrite(tag.data(), 1, head_bytes, out) != (size_t) head_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); return 1; }
-        out_bytes += head_bytes;
-    }
-
-    // ---- encode: the input, then four frames of silence, whole frames only (tomp3.cpp:906-1003) ----
-    // The reference refills a 256-frame buffer and appends the silence when it meets the end of the
-    // data; feeding whole frames of (data ++ 4 frames of zero bytes) is the same sequence of calls.
-    std::vector<unsigned char> audio, bs(128 * 1024);
-    {
-        std::vector<unsigned char> chunk(1 << 20);
-        while (audio.size() < indatasize) {
-            size_t want = chunk.size();
-            if (audio.size() + want > indatasize) want = (size_t) (indatasize - audio.size());
-            const size_t got = fread(chunk.data(), 1, want, in);
-            audio.insert(audio.end(), chunk.begin(), chunk.begin() + got);
-            if (got < want) break;
-        }
-    }
-    const uint64_t audio_bytes = audio.size();
-    audio.resize(audio.size() + 4 * (size_t) frame_in, 0);
-    std::vector<unsigned char> pcm(frame_in);
-    unsigned frames_expected = 0, crc = 0;
-    int toc_counter = 0;
-    for (size_t off = 0; off + frame_in <= audio.size(); off += frame_in) {
-        const HX_IN_OUT x = hx_enc_MP3_audio_encode(enc, audio.data() + off, bs.data());
-        frames_expected++;
-        if (x.out_bytes) {
-            if (fwrite(bs.data(), 1, x.out_bytes, out) != (size_t) x.out_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); return 1; }
-            crc = hx_xing_update_crc((unsigned short) crc, bs.data(), x.out_bytes);
-            out_bytes += x.out_bytes;
-        }
-        if (head_flags & 4) {
-            if (--toc_counter <= 0) {
-                const HX_INT_PAIR fb = hx_enc_get_frames_bytes(enc);
-                toc_counter = hx_xing_toc(xg, fb.a + 1, fb.b + head_bytes);
-            }
-        }
-    }
-    // ---- drain: silent frames until every submitted frame is out (tomp3.cpp:1020-1036) ----
-    memset(pcm.data(), 0, frame_in);
-    while (hx_enc_get_frames(enc) < frames_expected) {
-        const HX_IN_OUT x = hx_enc_MP3_audio_encode(enc, pcm.data(), bs.data());
-        if (fwrite(bs.data(), 1, x.out_bytes, out) != (size_t) x.out_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); return 1; }
-        crc = hx_xing_update_crc((unsigned short) crc, bs.data(), x.out_bytes);
-        out_bytes += x.out_bytes;
-    }
-    // ---- complete the tag in place (tomp3.cpp:1055-1072) ----
-    const unsigned frames = hx_enc_get_frames(enc);
-    if (xing_flag) {
-        const uint64_t samples_audio = audio_bytes / (uint64_t) (wi.channels * (wi.bits / 8));
-        hx_xing_update_info(xg, frames, (int) out_bytes, vbr_scale, nullptr, tag.data(), nullptr, nullptr, samples_audio,
-                            (unsigned) out_bytes, (unsigned) ec.freq_limit, (unsigned) wi.rate, (unsigned) ec.samprate, (unsigned short) crc);
-        if (out == stdout || fseek(out, 0, SEEK_SET) != 0) fprintf(stderr, "\n OUTPUT IS NOT SEEKABLE: TAG FRAME LEFT WITHOUT TOTALS");
-        else fwrite(tag.data(), 1, head_bytes, out);
-    }
-    fprintf(stderr, "\n %u frames, %llu bytes, %.2f kbps\n", frames, (unsigned long long) out_bytes, hx_enc_get_bitrate_float(enc));
-    if (out != stdout) fclose(out);
-    if (in != stdin) fclose(in);
-    hx_xing_destroy(xg);
-    hx_enc_destroy(enc);
-    return frames == 0 ? 1 : 0;
+    if (files.size() < 2) { usage(); return 1; }
+    return encode_one_file(files[0], files[1], opt);
 }

@@ -27,7 +27,7 @@ struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
     const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
     unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status; unsigned long long *prof;
-    unsigned char *packet; long long packet_stride; int *packet_bytes;
+    unsigned char *packet; long long packet_stride; int *packet_bytes; int *frame_stats;
 };
 __global__ void k_alloc(AllocArgs a);
 
@@ -49,6 +49,7 @@ struct hx_batch {
     HxGlobalTabs *d_gt = nullptr;
     HxStream *d_st = nullptr;
     float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
+    int *frame_stats = nullptr;         // caller's per-frame counters (device), optional
     unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
     bool any_dc = false;
@@ -170,6 +171,8 @@ extern "C" void hx_batch_packet_buffers(hx_batch *b, unsigned char *d_packet, lo
     b->pk_buf = d_packet; b->pk_stride = frame_stride; b->pk_bytes = d_packet_bytes;
 }
 
+extern "C" void hx_batch_frame_stats_buffer(hx_batch *b, int *d_stats) { b->frame_stats = d_stats; }
+
 extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
 {
     b->debug = on != 0;
@@ -211,7 +214,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
     a.msbase = b->d_msbase; a.bt = b->d_bt; a.btprev = b->d_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
-    a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes;
+    a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -276,6 +279,35 @@ extern "C" int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nfr
                                         long long out_stride, int *out_bytes)
 {
     return encode_host(b, pcm, 0, nframes, out, out_stride, out_bytes);
+}
+
+// host-buffer call that also returns the per-frame counters (see hx_batch_frame_stats_buffer)
+extern "C" int hx_batch_encode_f32_host_stats(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
+                                              long long out_stride, int *out_bytes, int *stats)
+{
+    if (!b || !stats) return -1;
+    HIPCHK(hipSetDevice(b->device));
+    int *d_stats = nullptr;
+    const size_t n = sizeof(int) * (size_t) b->S * nframes * 2;
+    HIPCHK(hipMalloc((void **) &d_stats, n));
+    int *saved = b->frame_stats;
+    b->frame_stats = d_stats;
+    int r = encode_host(b, pcm, 1, nframes, out, out_stride, out_bytes);
+    b->frame_stats = saved;
+    if (r == 0 && hipMemcpy(stats, d_stats, n, hipMemcpyDeviceToHost) != hipSuccess) r = -1;
+    hipFree(d_stats);
+    return r;
+}
+
+// what CMp3Enc::L3_audio_encode_info_ec / _info_head would report for a control, without creating an
+// encoder (host only).  Returns 0 if the configuration is rejected.
+extern "C" int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *head_out)
+{
+    HxParams p;
+    if (!hx_resolve((const HxControl *) ec, &p)) return 0;
+    if (ec_out) memcpy(ec_out, &p.ec, sizeof(HxControl));
+    if (head_out) memcpy(head_out, &p.head_info, sizeof(HxMpegHead));
+    return 1;
 }
 
 extern "C" int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out,

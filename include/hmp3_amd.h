@@ -101,6 +101,16 @@ int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigne
    d_packet_bytes [nstreams][nframes]; frame_stride >= 36 + largest main data of a frame (2048 is
    always enough).  NULL switches them off.  Applies to the calls that follow. */
 void hx_batch_packet_buffers(hx_batch *b, unsigned char *d_packet, long long frame_stride, int *d_packet_bytes);
+/* optional per-frame counters of the batched calls: d_stats [nstreams][nframes][2] = the stream's
+   get_frames() / bytes emitted so far after each input frame, i.e. what a caller of the per-frame
+   API (CMp3Enc::L3_audio_encode_get_frames_bytes after every call) would have seen.  NULL = off. */
+void hx_batch_frame_stats_buffer(hx_batch *b, int *d_stats);
+/* fp32 host call that also returns those counters to a host array stats[nstreams][nframes][2] */
+int hx_batch_encode_f32_host_stats(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
+                                   long long out_stride, int *out_bytes, int *stats);
+/* the settings an encoder would run a control with (what L3_audio_encode_info_ec / _info_head report,
+   mp3enc.cpp:839-866), host only; 0 = configuration rejected */
+int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *head_out);
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
    there).  0 = healthy.  Synchronises. */
 int hx_batch_status(hx_batch *b);

@@ -112,6 +112,27 @@ def test_packet_variant_matches_oracle(kw):
     e.close()
 
 
+def test_cli_batch_mode_files_byte_identical_to_reference_cli(tmp_path):
+    """`hmp3amd -batch`: six files of different rates / sample formats / lengths encoded as one batch of streams;
+    every output file must equal what the reference CLI writes for that input alone"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden_cli as M
+    args = []
+    for name in M.BATCH_INPUTS:
+        seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
+        wav, mp3 = str(tmp_path / (name + ".wav")), str(tmp_path / (name + ".mp3"))
+        M.write_wav(wav, M.case_pcm(name), sr, as_float)
+        args += [wav, mp3]
+    r = subprocess.run([os.path.join(root, "hmp3_amd", "hmp3amd"), "-batch"] + args + M.BATCH_FLAGS, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    for name in M.BATCH_INPUTS:
+        got = open(str(tmp_path / (name + ".mp3")), "rb").read()
+        assert got == open(os.path.join(GOLD, "batch_" + name[4:] + ".mp3"), "rb").read(), name
+
+
 MONO = {
     "mono_cbr64": dict(bitrate=64, mode=3),
     "mono_vbr50": dict(mode=3),

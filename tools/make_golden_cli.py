@@ -76,6 +76,11 @@ def case_pcm(name):
     return pcm[:, 0].copy() if name in MONO else pcm
 
 
+# batch mode: these stereo inputs are encoded together by `hmp3amd -batch ... -V60 -HF2`; the reference encodes them one by one
+BATCH_FLAGS = ["-V60", "-HF2"]
+BATCH_INPUTS = ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc", "cli_vbr50_s24_44k", "cli_cbr128_u8_44k", "cli_vbr50_s32_48k"]
+
+
 if __name__ == "__main__":
     ref = os.path.join(ROOT, "oracle", "_ref", "hmp3")
     gold = os.path.join(ROOT, "tests", "golden")
@@ -89,4 +94,14 @@ if __name__ == "__main__":
         open(os.path.join(gold, name + ".mp3"), "wb").write(data)
         meta[name] = {"bytes": len(data), "flags": flags}
         print(name, len(data), "bytes")
+    for name in BATCH_INPUTS:
+        seed, nsamp, sr, as_float, bursts, flags = CASES[name]
+        with tempfile.TemporaryDirectory() as d:
+            wav, mp3 = os.path.join(d, "in.wav"), os.path.join(d, "out.mp3")
+            write_wav(wav, case_pcm(name), sr, as_float)
+            subprocess.run([ref, wav, mp3] + BATCH_FLAGS, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            data = open(mp3, "rb").read()
+        open(os.path.join(gold, "batch_" + name[4:] + ".mp3"), "wb").write(data)
+        meta["batch_" + name[4:]] = {"bytes": len(data), "flags": BATCH_FLAGS}
+        print("batch_" + name[4:], len(data), "bytes")
     json.dump(meta, open(os.path.join(gold, "cli.json"), "w"), indent=1)
