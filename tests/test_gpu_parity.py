@@ -325,6 +325,49 @@ def test_stress_signals_rare_paths(name, kw):
     b.close()
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=64), dict(vbr_mnr=80), dict(bitrate=56, samprate=32000)], ids=["cbr128", "vbr80", "cbr112_32k"])
+def test_long_run_many_ragged_calls(kw):
+    """1500 frames through calls of 1..37 frames, s16 and fp32 calls interleaved: the pending-frame carry
+    between calls, the CBR padding sequence and the reservoir never drift from the oracle"""
+    sr = kw.get("samprate", 44100)
+    F = 1500
+    pcm = np.stack([synth.stream_pcm(40 + i, F, sr=sr, rho=RHOS[i % 4], bursts=(i & 1) == 1) for i in range(3)])
+    b = api().Batch(api().default_control(**kw), nstreams=3, max_frames=37)
+    rng = np.random.default_rng(3)
+    got = [b"", b"", b""]
+    f = 0
+    while f < F:
+        n = int(min(F - f, rng.integers(1, 38)))
+        chunk = pcm[:, f * 1152:(f + n) * 1152]
+        out = b.encode_host(chunk.astype(np.float32) if (f // 7) & 1 else chunk)
+        for s in range(3):
+            got[s] += out[s]
+        f += n
+    assert b.status() == 0
+    for s in range(3):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    fb = [b.frames_bytes(s) for s in range(3)]
+    assert all(x[1] == len(got[i]) and F - 12 <= x[0] <= F for i, x in enumerate(fb))
+    b.close()
+
+
+def test_api_misuse_fails_loudly_and_leaves_the_batch_usable():
+    a = api()
+    with pytest.raises(RuntimeError):           # mono and stereo streams cannot share a batch
+        a.Batch([a.default_control(bitrate=64), a.default_control(bitrate=64, mode=3)], nstreams=2, max_frames=4)
+    with pytest.raises(RuntimeError):           # dual channel is not built
+        a.Batch(a.default_control(bitrate=64, mode=2), nstreams=1, max_frames=4)
+    b = a.Batch(a.default_control(bitrate=64), nstreams=2, max_frames=4)
+    pcm = np.stack([synth.stream_pcm(5, 8), synth.stream_pcm(6, 8)])
+    with pytest.raises(RuntimeError):           # more frames than the batch was created for
+        b.encode_host(pcm)
+    first = b.encode_host(pcm[:, :4 * 1152])    # the failed call consumed nothing
+    second = b.encode_host(pcm[:, 4 * 1152:])
+    for s in range(2):
+        assert first[s] + second[s] == oracle_bytes(dict(bitrate=64), pcm[s], 8)
+    b.close()
+
+
 def test_cmp3enc_surface_single_stream():
     """the CMp3Enc-compatible entry points: init return values, per-frame encode, getters"""
     a = api()
