@@ -66,6 +66,8 @@ typedef struct {
     int framebytes, remainder, divisor, main_framebytes, side_bytes, sf_bit_max, AveTargetBits;
     int ms_flag, hf_flag, vbr_flag, short_block_threshold, filter_dc;
     int nchan;                  /* 1 = mono (mode 3), 2 = stereo / joint stereo */
+    int h_id;                   /* 1 = MPEG-1 (32 / 44.1 / 48 kHz), 0 = MPEG-2 LSF (16 / 22.05 / 24 kHz): one granule per frame */
+    int tix;                    /* row of the band tables: h_sr_index + 3 * (1 - h_id) */
     float filter_alpha;
     int ivbr_min, ivbr_max, vbr_main_framebytes[16], vbr_framebytes[16], vbr_pool_target;
     int initialMNR, test1, taperNT[22];
@@ -150,7 +152,7 @@ typedef struct hxo_encoder {
     hxo_state s;
     hxo_frame_debug *dbg;
     unsigned char *packet;      /* set for the duration of hxo_encode_frame_packet */
-    int packet_bytes;
+    int packet_bytes, packet_bytes2[2];    /* MPEG-2: two packets per call, back to back */
 } hxo_encoder;
 void hxo_set_debug(hxo_encoder *e, hxo_frame_debug *d);
 int hxo_sizeof_frame_debug(void);
@@ -165,7 +167,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec);
 int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out);
 /* 16-bit entry (MP3_audio_encode with source_bits=16, mp3enc.cpp:2812; srcc.cpp:824-828) */
 int hxo_encode_frame_s16(hxo_encoder *e, const int16_t *pcm, unsigned char *out);
-int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out, unsigned char *packet, int *packet_bytes);
+int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out, unsigned char *packet, int nbytes[2]);
 unsigned hxo_frames_out(const hxo_encoder *e);
 unsigned hxo_bytes_out(const hxo_encoder *e);
 void hxo_default_control(hxo_control *ec);      /* test/tomp3.cpp:357-384 */
@@ -181,6 +183,7 @@ void  hxo_hybrid_long(const hxo_params *p, const float *prev, const float *cur, 
 void  hxo_hybrid_short(const hxo_params *p, const float *prev, const float *cur, float *xr, int nsb);   /* hwin.c:228 */
 void  hxo_antialias(const hxo_params *p, float *xr, int nsb);   /* hwin.c:298 */
 int   hxo_attack_detect(const float *samp, int eng[32], int short_flag_prev);   /* detect.c:53 */
+int   hxo_attack_detect_lsf(const float *samp, int eng[32], int short_flag_prev);       /* detect.c:147 */
 void  hxo_psy_long(const hxo_params *p, const float *xr, float *ecsave, hxo_sigmask *sm, int block_type);   /* emap.c:96 + spdsmr.c:188 */
 void  hxo_psy_short(const hxo_params *p, const float *xr, float *ecsave, hxo_sigmask *sm, int block_type_prev);   /* emap.c:61 + spdsmr.c:64 */
 int   hxo_ms_metric_long(hxo_encoder *e, const float x[2][576]);    /* bitallo3.cpp:682 */
@@ -203,6 +206,8 @@ int  hxo_pack_sf_long(hxo_bitw *w, const hxo_scalefact *sf);      /* l3pack.c:15
 int  hxo_pack_sf_short(hxo_bitw *w, const hxo_scalefact *sf);     /* l3pack.c:218 */
 int  hxo_pack_huff(hxo_bitw *w, const hxo_gr *g, const int *ix, const unsigned char *sign);  /* l3pack.c:946 */
 void hxo_pack_side(unsigned char out[32], int mode, const int scfsi[2], hxo_gr gr[2][2], int nchan);      /* l3pack.c:1123 */
+void hxo_pack_side_lsf(unsigned char out[32], int mode, hxo_gr gr[2], int nchan);      /* l3pack.c:1189 */
+int  hxo_pack_sf_lsf(hxo_bitw *w, const hxo_scalefact *sf, int block_type);           /* l3pack.c:561,732 */
 
 #ifdef __cplusplus
 }

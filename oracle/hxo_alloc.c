@@ -440,6 +440,13 @@ static void sf_final(ba_t *b, int ch)
 {
     const hxo_params *p = b->p;
     int i, s, sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, scale, pre;
+    if (!p->h_id) {     /* fnc_sf_final_MPEG2 (bitallo3.cpp:1860-1888): no pre-emphasis in an LSF granule */
+        for (i = 0; i < p->nsf[ch]; i++)
+            if (b->active_sf[ch][i]) sp0 |= (sf_limit_hi(0, 0, i) - b->sf[ch][i]);
+        b->preemp[ch] = 0;
+        b->scale[ch] = (sp0 >= 0) ? 0 : 1;
+        return;
+    }
     for (i = 0; i < p->nsf[ch]; i++)
         if (b->active_sf[ch][i]) {
             s = b->sf[ch][i];

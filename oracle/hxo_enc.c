@@ -29,11 +29,29 @@ void hxo_default_control(hxo_control *ec)
 }
 
 static const int br_mpeg1_l3[16] = {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, -1};
+static const int br_mpeg2_l3[16] = {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, -1};
 
 /* mp3enc.cpp:964-1041 (MPEG-1 half) */
 static void gen_vbr_table(hxo_params *p, int max_tot_bitrate)
 {
     int i;
+    if (p->h_id == 0) {     /* mp3enc.cpp:1006-1040 */
+        for (i = 1; i < 15; i++) {
+            int mb = 72000 * br_mpeg2_l3[i] / p->samprate;
+            p->vbr_framebytes[i] = mb;
+            p->vbr_main_framebytes[i] = mb - 4 - p->side_bytes;
+        }
+        p->vbr_framebytes[15] = p->vbr_main_framebytes[15] = 9999999;
+        p->vbr_pool_target = 128;
+        for (i = 14; i >= 2; i--) {
+            if (max_tot_bitrate >= br_mpeg2_l3[i]) break;
+            p->vbr_pool_target = (p->vbr_pool_target + 255) >> 1;
+        }
+        p->ivbr_max = i;
+        p->ivbr_min = 1;
+        p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / p->nchan) - p->sf_bit_max;
+        return;
+    }
     for (i = 1; i < 15; i++) {
         int mb = 144000 * br_mpeg1_l3[i] / p->samprate;
         p->vbr_framebytes[i] = mb;
@@ -94,7 +112,9 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     }
     h_id = k >> 2;
     p->h_sr_index = k & 3;
-    if (h_id != 1) return 0;                /* MPEG-2 rates: out of scope */
+    if (sr_all[k] == 1) return 0;
+    p->h_id = h_id;
+    p->tix = p->h_sr_index + 3 * (1 - h_id);
     if (ec.mode == 2) return 0;             /* dual channel (CBitAllo1): out of scope */
     p->h_mode = ec.mode;
     p->nchan = (ec.mode == 3) ? 1 : 2;
@@ -105,24 +125,31 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     bitrate = ec.bitrate;
     if (bitrate < 8) bitrate = 8;
     if (ec.mode != 3) bitrate = 2 * bitrate;
-    if (bitrate > 320) bitrate = 320;
+    if (bitrate > (h_id ? 320 : 160)) bitrate = h_id ? 320 : 160;
     p->h_br_index = 0;
-    for (i = 1; br_mpeg1_l3[i] >= 0; i++) if (br_mpeg1_l3[i] == bitrate) p->h_br_index = i;
+    for (i = 1; (h_id ? br_mpeg1_l3 : br_mpeg2_l3)[i] >= 0; i++) if ((h_id ? br_mpeg1_l3 : br_mpeg2_l3)[i] == bitrate) p->h_br_index = i;
     p->totbitrate = bitrate;
     p->h_cr = ec.cr_bit;
     p->h_original = ec.original;
     /* pack_head_local (mp3enc.cpp:874-895): sync, id=1, layer III, no CRC */
     p->head[0] = 0xFF;
-    p->head[1] = (unsigned char) (0xF0 | (1 << 3) | (1 << 1) | 1);
+    p->head[1] = (unsigned char) (0xF0 | (h_id << 3) | (1 << 1) | 1);
     p->head[2] = (unsigned char) ((p->h_br_index << 4) | (p->h_sr_index << 2));
     p->head[3] = (unsigned char) ((p->h_mode << 6) | (mode_ext << 4) | (p->h_cr << 3) | (p->h_original << 2));
 
-    p->nband = hxo_sfb_long_edge(p->h_sr_index, 21);
+    p->nband = hxo_sfb_long_edge(p->tix, 21);
     p->nsb = (p->nband + 17) / 18;
-    nsbstereo = 12 * p->totbitrate / 32 - 20;
-    nsbstereo = HXO_MIN(nsbstereo, 32);
-    nsbstereo = HXO_MAX(nsbstereo, 3);
-    if (p->totbitrate >= 96) nsbstereo = 32;
+    if (h_id == 0) {
+        nsbstereo = 7 * p->totbitrate / 16 - 7;
+        nsbstereo = HXO_MIN(nsbstereo, 32);
+        nsbstereo = HXO_MAX(nsbstereo, 3);
+        if (p->totbitrate >= 48) nsbstereo = 32;
+    } else {
+        nsbstereo = 12 * p->totbitrate / 32 - 20;
+        nsbstereo = HXO_MIN(nsbstereo, 32);
+        nsbstereo = HXO_MAX(nsbstereo, 3);
+        if (p->totbitrate >= 96) nsbstereo = 32;
+    }
     if (ec.vbr_flag) nsbstereo = 32;
     if (ec.nsbstereo > 0) {
         nsbstereo = ec.nsbstereo;
@@ -130,14 +157,22 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         if (nsbstereo > 32) nsbstereo = 32;
     }
     if (nsbstereo > p->nsb) nsbstereo = p->nsb;
-    p->samprate = sr_all[4 + p->h_sr_index];
+    p->samprate = sr_all[4 * h_id + p->h_sr_index];
     p->divisor = p->samprate;
-    p->framebytes = 144000 * p->totbitrate / p->divisor;
-    p->remainder = (144000 * p->totbitrate) % p->divisor;
-    p->side_bytes = (p->h_mode == 3) ? 17 : 32;
-    p->main_framebytes = p->framebytes - 4 - p->side_bytes;
     p->sf_bit_max = 3 * (6 * 4 + 6 * 3);
-    p->AveTargetBits = 8 * p->main_framebytes / 2;
+    if (h_id) {
+        p->framebytes = 144000 * p->totbitrate / p->divisor;
+        p->remainder = (144000 * p->totbitrate) % p->divisor;
+        p->side_bytes = (p->h_mode == 3) ? 17 : 32;
+        p->main_framebytes = p->framebytes - 4 - p->side_bytes;
+        p->AveTargetBits = 8 * p->main_framebytes / 2;
+    } else {        /* one granule per frame (mp3enc.cpp:462-481) */
+        p->framebytes = (144000 / 2) * p->totbitrate / p->divisor;
+        p->remainder = ((144000 / 2) * p->totbitrate) % p->divisor;
+        p->side_bytes = (p->h_mode == 3) ? 9 : 17;
+        p->main_framebytes = p->framebytes - 4 - p->side_bytes;
+        p->AveTargetBits = 8 * p->main_framebytes;
+    }
     if (p->h_mode != 3) p->AveTargetBits >>= 1;
     p->AveTargetBits -= p->sf_bit_max;
 
@@ -154,7 +189,14 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         nsb_user_flag = 1;
     }
     nsb_limit_user = HXO_MIN(nsb_limit_user1, nsb_limit_user2);
-    if (ec.vbr_flag) {
+    if (ec.vbr_flag && h_id == 0) {         /* mp3enc.cpp:518-533 */
+        freq_limit = 7500 + 50 * ec.vbr_mnr;
+        if (ec.vbr_mnr <= 5) freq_limit = 7500;
+        freq_limit = HXO_MIN(freq_limit, ((int) ((0.96f * 0.5f) * p->samprate)));
+        freq_limit = hxo_nearest_sf_band_freq(p->tix, p->samprate, freq_limit);
+        tmp = (64 * freq_limit + (p->samprate / 2)) / p->samprate;
+        freq_limit = (tmp * p->samprate) / 64;
+    } else if (ec.vbr_flag) {
         freq_limit = 12000 + 80 * ec.vbr_mnr;
         if (ec.vbr_mnr <= 5) freq_limit = 12000;
         freq_limit = HXO_MIN(freq_limit, ((int) ((0.96f * 0.5f) * p->samprate)));
@@ -164,7 +206,16 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         float chan_bitrate = (float) p->totbitrate;
         if (p->h_mode != 3) chan_bitrate = (float) (0.5 * chan_bitrate);
         chan_bitrate = factor[p->h_mode] * chan_bitrate;
-        freq_limit = (int) (187.97 * chan_bitrate);
+        if (p->samprate < 32000) {
+            if (chan_bitrate <= 32.0f) freq_limit = (int) (752.0 + 203.0 * chan_bitrate);
+            else if (chan_bitrate <= 42.7f) freq_limit = (int) (-2967.0 + 327.0 * chan_bitrate);
+            else freq_limit = 11000;
+        } else freq_limit = (int) (187.97 * chan_bitrate);
+        if (h_id == 0) {                    /* mp3enc.cpp:537-545 */
+            freq_limit = hxo_nearest_sf_band_freq(p->tix, p->samprate, freq_limit);
+            tmp = (64 * freq_limit + (p->samprate / 2)) / p->samprate;
+            freq_limit = (tmp * p->samprate) / 64;
+        }
     }
     if (nsb_user_flag) p->nsb_limit = nsb_limit_user;
     else p->nsb_limit = (64 * HXO_MAX(freq_limit, 1000) + p->samprate / 2) / p->samprate;
@@ -192,9 +243,9 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
 
     /* band tables */
     for (i = 0; i < 22; i++)
-        p->nBand_l_iso[i] = p->nBand_l[i] = hxo_sfb_long_edge(p->h_sr_index, i + 1) - hxo_sfb_long_edge(p->h_sr_index, i);
+        p->nBand_l_iso[i] = p->nBand_l[i] = hxo_sfb_long_edge(p->tix, i + 1) - hxo_sfb_long_edge(p->tix, i);
     for (i = 0; i < 13; i++)
-        p->nBand_s[i] = hxo_sfb_short_edge(p->h_sr_index, i + 1) - hxo_sfb_short_edge(p->h_sr_index, i);
+        p->nBand_s[i] = hxo_sfb_short_edge(p->tix, i + 1) - hxo_sfb_short_edge(p->tix, i);
     hxo_init_transform_tables(p);
     hxo_init_psy_long(p);
     hxo_init_psy_short(p);
@@ -214,7 +265,8 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         if (p->initialMNR > 1500) p->initialMNR = 1500;
     } else {
         tmp = p->totbitrate / p->nchan;
-        p->initialMNR = 125 * (tmp - 32) / 8;
+        if (h_id) p->initialMNR = 125 * (tmp - 32) / 8;
+        else p->initialMNR = 10 * ((30 * tmp) / 8 - 70);
         if (p->initialMNR < 0) p->initialMNR = 0;
         if (p->initialMNR > 1000) p->initialMNR = 1000;
     }
@@ -233,8 +285,8 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     /* CBitAllo3::BitAlloInit (bitallo3.cpp:288-480) */
     s->MNR = p->initialMNR;
     s->PoolFraction = p->vbr_flag ? 614 : 0;
-    p->nsf3[0] = p->nsf2[0] = p->nsf[0] = hxo_sfbl_limit(p->h_sr_index, p->band_limit);
-    p->nsf3[1] = p->nsf2[1] = p->nsf[1] = hxo_sfbl_limit(p->h_sr_index, p->band_limit_stereo);
+    p->nsf3[0] = p->nsf2[0] = p->nsf[0] = hxo_sfbl_limit(p->tix, p->band_limit);
+    p->nsf3[1] = p->nsf2[1] = p->nsf[1] = hxo_sfbl_limit(p->tix, p->band_limit_stereo);
     if (p->hf_flag) { p->nsf2[0] = 22; p->nBand_l[21] = 100; }
     if (p->hf_flag & 2) { p->nsf3[0] = 22; p->nsf3[1] = 22; }
     for (k = 0, i = 0; i < 22; i++) { p->startBand_l[i] = k; k += p->nBand_l[i]; }
@@ -257,7 +309,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         if (p->vbr_flag) for (i = 11; i < 22; i++) p->taperNT[i] = HXO_MIN(p->taperNT[i], p->initialMNR);
         for (i = 0; i < 21; i++) p->taperNT[i] -= 10 * mnrGOLD[i];
     }
-    p->initialMNR = s->MNR = s->MNR + MNRbias;
+    p->initialMNR = s->MNR = s->MNR + MNRbias - (h_id ? 0 : 300);      /* bitallo3.cpp:446-453 */
     for (i = 0; i < 22; i++) if (p->nBand_l[i] != 0) p->rnBand_l[i] = (1.0f / p->nBand_l[i]);
     s->hf_quant = 0;
     s->gsf_hf = -1;
@@ -319,8 +371,10 @@ static void blocktype_select(hxo_encoder *e, int igr)
     static const int bt_sel[4][2][2] = {{{0, 1}, {2, 2}}, {{3, 2}, {2, 2}}, {{3, 2}, {2, 2}}, {{0, 1}, {2, 2}}};
     hxo_state *s = &e->s;
     int prev_gr = igr ^ 1, ahead = (s->igrx + 1) & 3, v1, v2, sf = 0;
-    v1 = hxo_attack_detect(s->sample[0][ahead], s->attack_buf[0], s->short_flag_next[prev_gr]);
-    v2 = hxo_attack_detect(s->sample[1][ahead], s->attack_buf[1], s->short_flag_next[prev_gr]);
+    /* the _MPEG2 selectors (mp3enc.cpp:1363-1395,1444-1488) differ only in the detector; the mono ones only use v1 */
+    int (*detect)(const float *, int *, int) = e->p.h_id ? hxo_attack_detect : hxo_attack_detect_lsf;
+    v1 = detect(s->sample[0][ahead], s->attack_buf[0], s->short_flag_next[prev_gr]);
+    v2 = (e->p.nchan == 2) ? detect(s->sample[1][ahead], s->attack_buf[1], s->short_flag_next[prev_gr]) : 0;
     s->last_attack[igr][0] = v1; s->last_attack[igr][1] = v2;
     if (v1 > e->p.short_block_threshold) sf = 1;
     if (v2 > e->p.short_block_threshold) sf = 1;
@@ -501,6 +555,169 @@ static int encode_single(hxo_encoder *e, hxo_bitw *w)
     return 0;
 }
 
+/* encode_jointB_MPEG2 (mp3enc.cpp:1832-1907) and encode_singleB_MPEG2 (:1977-2027): one granule = one frame */
+static int encode_granule_lsf(hxo_encoder *e, hxo_bitw *w, int igr)
+{
+    hxo_state *s = &e->s;
+    const hxo_params *p = &e->p;
+    int ch, bits, bit_pool, bit_min, bit_max, ba_min, ba_max, sf_bits, ms = 0, bt;
+
+    bit_pool = s->byte_pool << 3;
+    bit_max = s->byte_max << 3;
+    bit_min = s->byte_min << 3;
+    if (p->nchan == 2 && s->byte_pool > 245) bit_min += 40;
+    ba_max = bit_max;
+    if (ba_max > 4095) ba_max = 4095;
+    sf_bits = p->nchan * p->sf_bit_max;
+    ba_max -= sf_bits;
+    ba_min = bit_min - sf_bits;
+
+    blocktype_select(e, igr);
+    transform_granule(e, igr);
+    bt = s->block_type[igr];
+    if (p->ms_flag) {
+        int m1;
+        if (bt == 2) { s->ms_correlation_memory = 0; m1 = hxo_ms_metric_short(e, (const float (*)[576]) s->xr[igr]); }
+        else m1 = hxo_ms_metric_long(e, (const float (*)[576]) s->xr[igr]);
+        s->last_ms_metric[igr] = m1;
+        if (m1 >= 0) ms = 1;
+    }
+    if (e->dbg) {
+        e->dbg->ms = ms; e->dbg->byte_pool = s->byte_pool;
+        e->dbg->block_type[igr] = bt;
+        memcpy(e->dbg->xr_pre[igr], s->xr[igr], sizeof(s->xr[igr]));
+    }
+    for (ch = 0; ch < p->nchan; ch++) {
+        if (bt != 2) hxo_psy_long(p, s->xr[igr][ch], s->ecsave[ch], s->sig_mask[ch], bt);
+        else hxo_psy_short(p, s->xr[igr][ch], s->ecsave[ch], s->sig_mask[ch], s->block_type_prev[igr]);
+    }
+    s->gr[igr][0].block_type = s->gr[igr][1].block_type = bt;
+    hxo_bitallo_long(e, s->xr[igr], s->sig_mask, ba_min, p->nchan * p->AveTargetBits, ba_max, bit_pool,
+                     s->sf[igr], s->gr[igr], ms);
+    if (e->dbg) {
+        memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
+        memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+    }
+    for (ch = 0; ch < p->nchan; ch++) {
+        hxo_gr *g = &s->gr[igr][ch];
+        bits = 0;
+        g->scalefac_compress = 0;
+        if (p->nchan == 2 ? g->aux_not_null : g->aux_bits) {
+            g->scalefac_compress = hxo_pack_sf_lsf(w, &s->sf[igr][ch], bt);
+            bits = hxo_pack_huff(w, g, s->ix[ch], s->signx[ch]);
+        }
+        g->part2_3_length = bits;
+    }
+    return ms;
+}
+
+/* L3_audio_encode_MPEG2 (mp3enc.cpp:2483-2593) and L3_audio_encode_vbr_MPEG2 (:2337-2479): the 1152-sample block
+   already shifted in by input_filter becomes two single-granule frames */
+static int encode_block_lsf(hxo_encoder *e, unsigned char *out)
+{
+    hxo_state *s = &e->s;
+    const hxo_params *p = &e->p;
+    hxo_bitw w;
+    unsigned char *out0 = out, *pk = e->packet;
+    int igr, bytes, raw_bytes, pad, ms, ibr, mf, bytesout;
+
+    for (igr = 0; igr < 2; igr++) {
+        pad = 0; ibr = 0;
+        if (!p->vbr_flag) {
+            s->padcount -= p->remainder;
+            if (s->padcount <= 0) { s->padcount += p->divisor; pad = 1; }
+            s->frame_mf_bytes[s->side_p1] = p->main_framebytes + pad;
+        }
+        s->frame_main_pos[s->side_p1] = s->main_tot;
+        s->byte_pool = (int) (s->mf_tot - s->main_tot);
+        if (!p->vbr_flag) {
+            s->byte_max = p->main_framebytes + pad + s->byte_pool;
+            s->byte_min = s->byte_max - 255;
+        } else {
+            s->byte_max = p->vbr_main_framebytes[p->ivbr_max] + s->byte_pool;
+            s->byte_min = p->vbr_main_framebytes[p->ivbr_min] + s->byte_pool - 255;
+        }
+        hxo_bw_init(&w, s->main_buf + s->main_p1);
+        ms = encode_granule_lsf(e, &w, igr);
+        s->last_ms = ms;
+        s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms);
+        bytes = hxo_bw_flush(&w);
+        assert(bytes <= s->byte_max);
+        if (e->dbg) {
+            memcpy(e->dbg->gr[igr], s->gr[igr], sizeof(s->gr[igr]));
+            e->dbg->MNR_after = s->MNR;
+            e->dbg->main_bytes = bytes;
+        }
+        if (p->vbr_flag) {
+            int bytes2 = bytes - s->byte_pool, bytes3 = bytes2 + p->vbr_pool_target;
+            int side_dp = (s->side_p1 - s->side_p0) & 31;
+            for (ibr = p->ivbr_min; ibr <= p->ivbr_max; ibr++) if (bytes2 <= p->vbr_main_framebytes[ibr]) break;
+            if (side_dp < 10) {
+                for (; ibr <= p->ivbr_max; ibr++) if (bytes3 < p->vbr_main_framebytes[ibr + 1]) break;
+            } else if (side_dp > 15) {      /* many frames span the pool: drain it through byte_min padding */
+                if (side_dp > 24) s->byte_min = p->vbr_main_framebytes[p->ivbr_min] + s->byte_pool;
+                else s->byte_min = p->vbr_main_framebytes[p->ivbr_min] + (s->byte_pool >> 4);
+            }
+            if (ibr > p->ivbr_max) ibr = p->ivbr_max;
+            s->br_index_buf[s->side_p1] = (unsigned char) ibr;
+            s->frame_mf_bytes[s->side_p1] = p->vbr_main_framebytes[ibr];
+        }
+        raw_bytes = bytes;
+        if (bytes < s->byte_min) {
+            memset(s->main_buf + s->main_p1 + bytes, 0, s->byte_min - bytes);
+            bytes = s->byte_min;
+        }
+        hxo_pack_side_lsf(s->side_buf[s->side_p1], p->h_mode, s->gr[igr], p->nchan);
+        if (pk) {       /* mp3enc.cpp:3352-3362, :3196-3206: the two packets back to back */
+            pk[0] = p->head[0]; pk[1] = p->head[1]; pk[2] = p->head[2]; pk[3] = p->head[3];
+            if (pad) pk[2] |= 2;
+            pk[3] = (unsigned char) ((pk[3] & 0xCF) | ((ms + ms) << 4));
+            memcpy(pk + 4, s->side_buf[s->side_p1], p->side_bytes);
+            memcpy(pk + 4 + p->side_bytes, s->main_buf + s->main_p1, (size_t) raw_bytes);
+            e->packet_bytes2[igr] = 4 + p->side_bytes + raw_bytes;
+            pk += e->packet_bytes2[igr];
+        }
+        s->main_tot += bytes;
+        s->main_bytes += bytes;
+        s->main_p1 += bytes;
+        s->mf_tot += p->vbr_flag ? p->vbr_main_framebytes[ibr] : p->main_framebytes + pad;
+        s->side_p1 = (s->side_p1 + 1) & 31;
+
+        while (s->side_p0 != s->side_p1) {
+            int main_data_begin;
+            mf = s->frame_mf_bytes[s->side_p0];
+            if (s->main_bytes < mf) break;
+            s->tot_frames_out++;
+            main_data_begin = (int) (s->main_sent - s->frame_main_pos[s->side_p0]);
+            assert(main_data_begin >= 0 && main_data_begin < 256);
+            s->main_sent += mf;
+            out[0] = p->head[0]; out[1] = p->head[1]; out[2] = p->head[2]; out[3] = p->head[3];
+            if (!p->vbr_flag) { if (mf - p->main_framebytes) out[2] |= 2; }
+            else out[2] = (unsigned char) ((out[2] & 0x0F) | (s->br_index_buf[s->side_p0] << 4));
+            out[3] = (unsigned char) ((out[3] & 0xCF) | (s->mode_ext_buf[s->side_p0] << 4));
+            out += 4;
+            s->side_buf[s->side_p0][0] = (unsigned char) main_data_begin;
+            memmove(out, s->side_buf[s->side_p0], p->side_bytes);
+            out += p->side_bytes;
+            memmove(out, s->main_buf + s->main_p0, mf);
+            out += mf;
+            s->main_bytes -= mf;
+            s->main_p0 += mf;
+            s->side_p0 = (s->side_p0 + 1) & 31;
+        }
+        if (s->main_p1 > 16384) {
+            s->main_p1 = s->main_p1 - s->main_p0;
+            memmove(s->main_buf, s->main_buf + s->main_p0, s->main_p1);
+            s->main_p0 = 0;
+        }
+    }
+    e->packet_bytes = e->packet ? e->packet_bytes2[0] + e->packet_bytes2[1] : 0;
+    bytesout = (int) (out - out0);
+    s->tot_bytes_out += bytesout;
+    s->ave_tot_bytes_out = s->ave_tot_bytes_out + ((((bytesout << 8) - s->ave_tot_bytes_out)) >> 6);
+    return bytesout;
+}
+
 /* mp3enc.cpp:2230-2333 (CBR) and :2106-2226 (VBR) */
 int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
 {
@@ -511,6 +728,7 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
     int bytes, raw_bytes, pad = 0, ms, ibr = 0, mf, bytesout;
 
     input_filter(e, pcm);
+    if (!p->h_id) return encode_block_lsf(e, out);
     if (!p->vbr_flag) {
         s->padcount -= p->remainder;
         if (s->padcount <= 0) { s->padcount += p->divisor; pad = 1; }
@@ -601,14 +819,15 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
 }
 
 /* CMp3Enc::L3_audio_encode_Packet: also returns the frame as a self-contained packet */
-int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out, unsigned char *packet, int *packet_bytes)
+int hxo_encode_frame_packet(hxo_encoder *e, const float *pcm, unsigned char *out, unsigned char *packet, int nbytes[2])
 {
     int n;
     e->packet = packet;
-    e->packet_bytes = 0;
+    e->packet_bytes = e->packet_bytes2[0] = e->packet_bytes2[1] = 0;
     n = hxo_encode_frame(e, pcm, out);
     e->packet = 0;
-    *packet_bytes = e->packet_bytes;
+    if (e->p.h_id) { nbytes[0] = e->packet_bytes; nbytes[1] = 0; }     /* mp3enc.cpp:3068-3069 */
+    else { nbytes[0] = e->packet_bytes2[0]; nbytes[1] = e->packet_bytes2[1]; }     /* mp3enc.cpp:3363: two packets */
     return n;
 }
 

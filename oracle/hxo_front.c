@@ -264,6 +264,29 @@ int hxo_attack_detect(const float *sample, int eng[32], int short_flag_prev)
     return m;
 }
 
+/* detect.c:147-228, the MPEG-2 variant: subbands 8..27, rise over the four preceding values */
+int hxo_attack_detect_lsf(const float *sample, int eng[32], int short_flag_prev)
+{
+    int i, j, k, m = 0;
+    memmove(eng, eng + 9, 23 * sizeof(int));
+    for (k = 0, j = 23; k < 9; k++, j++) {
+        const float *y = sample + 18 * 8 + 2 * k;
+        float sum = 7.0e4f, x;
+        for (i = 0; i < 20; i++, y += 18) {
+            x = y[0] * y[0]; sum += x;
+            x = y[1] * y[1]; sum += x;
+        }
+        eng[j] = hxo_mblog(sum);
+    }
+    for (j = short_flag_prev ? 18 : 17; j < 29; j++) {
+        int a1 = HXO_MAX(eng[j - 4], eng[j - 5]);
+        int a2 = HXO_MAX(eng[j - 2], eng[j - 3]);
+        int a = HXO_MAX(a1, a2);
+        m = HXO_MAX(m, eng[j] - a);
+    }
+    return m;
+}
+
 /* test taps: when set, hxo_psy_long also stores etab and the unclamped thresholds */
 float *hxo_tap_etab, *hxo_tap_thr;
 

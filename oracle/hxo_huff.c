@@ -293,6 +293,39 @@ int hxo_pack_sf_short(hxo_bitw *w, const hxo_scalefact *sf)
     return sc;
 }
 
+/* slen for one MPEG-2 scalefactor group (l3pack.c:636-667) */
+static int lsf_slen(int sfmax, int cap)
+{
+    int n = 1, s;
+    sfmax++;
+    for (s = 0; s < cap; s++) { if (sfmax <= n) break; n += n; }
+    return s;
+}
+
+/* l3pack.c:561-729 (long) and :732-930 (short), the non-intensity branch: four groups of 6/5/5/5 long
+   or 3/3/3/3 short bands, slen1..4 capped at 4/4/3/3, 9-bit scalefac_compress */
+int hxo_pack_sf_lsf(hxo_bitw *w, const hxo_scalefact *sf, int block_type)
+{
+    static const int edge_l[5] = {0, 6, 11, 16, 21}, edge_s[5] = {0, 3, 6, 9, 12}, cap[4] = {4, 4, 3, 3};
+    int i, k, g, m, slen[4];
+    w->bit_pos_start = bw_pos(w);
+    if (block_type == 2) {
+        for (g = 0; g < 4; g++) {
+            for (m = 0, k = 0; k < 3; k++) for (i = edge_s[g]; i < edge_s[g + 1]; i++) m = HXO_MAX(m, sf->s[k][i]);
+            slen[g] = lsf_slen(m, cap[g]);
+        }
+        for (g = 0; g < 4; g++)
+            for (i = edge_s[g]; i < edge_s[g + 1]; i++) for (k = 0; k < 3; k++) hxo_bw_put(w, sf->s[k][i], slen[g]);
+    } else {
+        for (g = 0; g < 4; g++) {
+            for (m = 0, i = edge_l[g]; i < edge_l[g + 1]; i++) m = HXO_MAX(m, sf->l[i]);
+            slen[g] = lsf_slen(m, cap[g]);
+        }
+        for (g = 0; g < 4; g++) for (i = edge_l[g]; i < edge_l[g + 1]; i++) hxo_bw_put(w, sf->l[i], slen[g]);
+    }
+    return slen[3] + (slen[2] << 2) + ((slen[1] + 5 * slen[0]) << 4);
+}
+
 /* l3pack.c:421-558: long blocks with scfsi reuse between granule 0 and 1 */
 int hxo_pack_sf_long_scfsi(hxo_bitw *w, int sf_save[21], const hxo_scalefact *sf, int igr,
                            int *pscfsi, int not_null)
@@ -404,5 +437,41 @@ void hxo_pack_side(unsigned char out[32], int mode, const int scfsi[2], hxo_gr g
             hxo_bw_put(&w, g->scalefac_scale, 1);
             hxo_bw_put(&w, g->count1table_select, 1);
         }
+    hxo_bw_flush(&w);
+}
+
+/* l3pack.c:1189-1246: one-granule MPEG-2 side info (stereo 17 bytes, mono 9); main_data_begin (8 bits) patched at emit */
+void hxo_pack_side_lsf(unsigned char out[32], int mode, hxo_gr gr[2], int nchan)
+{
+    hxo_bitw w;
+    int ch;
+    hxo_bw_init(&w, out);
+    hxo_bw_put(&w, 0, 8);
+    hxo_bw_put(&w, 0, mode == 3 ? 1 : 2);
+    for (ch = 0; ch < nchan; ch++) {
+        const hxo_gr *g = &gr[ch];
+        hxo_bw_put(&w, g->part2_3_length, 12);
+        hxo_bw_put(&w, g->big_values, 9);
+        hxo_bw_put(&w, g->global_gain, 8);
+        hxo_bw_put(&w, g->scalefac_compress, 9);
+        hxo_bw_put(&w, g->window_switching_flag, 1);
+        if (g->window_switching_flag) {
+            hxo_bw_put(&w, g->block_type, 2);
+            hxo_bw_put(&w, g->mixed_block_flag, 1);
+            hxo_bw_put(&w, g->table_select[0], 5);
+            hxo_bw_put(&w, g->table_select[1], 5);
+            hxo_bw_put(&w, g->subblock_gain[0], 3);
+            hxo_bw_put(&w, g->subblock_gain[1], 3);
+            hxo_bw_put(&w, g->subblock_gain[2], 3);
+        } else {
+            hxo_bw_put(&w, g->table_select[0], 5);
+            hxo_bw_put(&w, g->table_select[1], 5);
+            hxo_bw_put(&w, g->table_select[2], 5);
+            hxo_bw_put(&w, g->region0_count, 4);
+            hxo_bw_put(&w, g->region1_count, 3);
+        }
+        hxo_bw_put(&w, g->scalefac_scale, 1);
+        hxo_bw_put(&w, g->count1table_select, 1);
+    }
     hxo_bw_flush(&w);
 }

@@ -26,6 +26,7 @@ int hxo_sfb_long_edge(int sr_index, int i);
 int hxo_sfb_short_edge(int sr_index, int i);
 int hxo_sfbl_limit(int sr_index, int band_limit);
 int hxo_sfbs_limit(int sr_index, int band_limit);
+int hxo_nearest_sf_band_freq(int tix, int samprate, int freq);
 int hxo_samprate_mpeg1(int sr_index);
 void hxo_init_transform_tables(hxo_params *p);
 void hxo_init_psy_long(hxo_params *p);

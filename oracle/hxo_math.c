@@ -91,15 +91,35 @@ int hxo_huff_len(int t, int x, int y) { return HX_HUFF_LEN[HX_HUFF_OFF[t] + x * 
 int hxo_quada_code(int v) { return HX_QUADA_CODE[v]; }
 int hxo_quada_len(int v) { return HX_QUADA_LEN[v]; }
 
-/* ---- ISO 11172-3 Table B.8 scalefactor band edges, MPEG-1 (l3init.c:80-97) ---- */
-static const short sfb_long[3][23] = {
+/* ---- scalefactor band edges (l3init.c:56-99): rows 0..2 = ISO 11172-3 Table B.8 (MPEG-1: 44.1, 48,
+   32 kHz), rows 3..5 = ISO 13818-3 (MPEG-2 LSF: 22.05, 24, 16 kHz).  Row = sr_index + 3 * (1 - h_id). ---- */
+static const short sfb_long[6][23] = {
     {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 52, 62, 74, 90, 110, 134, 162, 196, 238, 288, 342, 418, 576},
     {0, 4, 8, 12, 16, 20, 24, 30, 36, 42, 50, 60, 72, 88, 106, 128, 156, 190, 230, 276, 330, 384, 576},
-    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 54, 66, 82, 102, 126, 156, 194, 240, 296, 364, 448, 550, 576}};
-static const short sfb_short[3][14] = {
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 54, 66, 82, 102, 126, 156, 194, 240, 296, 364, 448, 550, 576},
+    {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},
+    {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 114, 136, 162, 194, 232, 278, 332, 394, 464, 540, 576},
+    {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576}};
+static const short sfb_short[6][14] = {
     {0, 4, 8, 12, 16, 22, 30, 40, 52, 66, 84, 106, 136, 192},
     {0, 4, 8, 12, 16, 22, 28, 38, 50, 64, 80, 100, 126, 192},
-    {0, 4, 8, 12, 16, 22, 30, 42, 58, 78, 104, 138, 180, 192}};
+    {0, 4, 8, 12, 16, 22, 30, 42, 58, 78, 104, 138, 180, 192},
+    {0, 4, 8, 12, 18, 24, 32, 42, 56, 74, 100, 132, 174, 192},
+    {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 136, 180, 192},
+    {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 134, 174, 192}};
+
+/* l3init.c:148-172: frequency of the scalefactor band edge nearest to freq */
+int hxo_nearest_sf_band_freq(int tix, int samprate, int freq)
+{
+    int i, f, fout = freq, delta, deltamin = 999999;
+    float a = samprate / (2.0f * 576.0f);
+    for (i = 0; i < 21; i++) {
+        f = (int) (a * sfb_long[tix][i + 1] + 0.5f);
+        delta = abs(f - freq);
+        if (delta < deltamin) { deltamin = delta; fout = f; }
+    }
+    return fout;
+}
 static const int sr_mpeg1[3] = {44100, 48000, 32000};
 
 int hxo_sfb_long_edge(int sr_index, int i) { return sfb_long[sr_index][i]; }
@@ -328,7 +348,7 @@ void hxo_init_psy_short(hxo_params *p)
     x = 0.5f * p->samprate / 192;
     for (i = 0; i < 31; i++) {
         freq = x * 0.5f * (part[i] + part[i + 1]);
-        snr_factor[i] = (float) (0.7 * pow(10.0, -0.1 * interp(dbsnr, freq)));
+        snr_factor[i] = (float) ((p->h_id ? 0.7 : 2.8) * pow(10.0, -0.1 * interp(dbsnr, freq)));      /* amodini2.c:678-690 */
         bval[i] = f_to_bark(freq);
     }
     snr_factor[i] = 1.0f;

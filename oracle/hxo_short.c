@@ -32,7 +32,7 @@ void hxo_short_init(hxo_encoder *e)
     hxo_params *p = &e->p;
     int i;
     /* bitallos.cpp:128-200: band limits are passed in long-block lines */
-    p->nsfs = hxo_sfbs_limit(p->h_sr_index, p->band_limit / 3 - 10);
+    p->nsfs = hxo_sfbs_limit(p->tix, p->band_limit / 3 - 10);
     p->nbmax_s = p->startBand_s[p->nsfs];
     for (i = 0; i < 12; i++) p->look_log_cbwmb_s[i] = (int) (100.0f * hxo_dblog((float) p->nBand_s[i]));
     e->s.s_call_count = 0;
@@ -515,6 +515,7 @@ int hxo_bitallo_short(hxo_encoder *e, float xr[2][576], hxo_sigmask smarg[2][36]
     memset(b, 0, sizeof(*b));
     b->e = e; b->p = p;
     b->MNR = MNR;
+    if (!p->h_id) b->MNR = HXO_MIN(b->MNR, 850);      /* bitallos.cpp:214-217 */
     e->s.s_call_count++;
     b->ms_flag = ms_flag;
     b->xr = (float (*)[3][192]) xr;

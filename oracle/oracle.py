@@ -122,9 +122,10 @@ class OracleEncoder:
         """-> (bitstream bytes, reformatted packet bytes) of L3_audio_encode_Packet"""
         frame = np.ascontiguousarray(frame, dtype=np.float32)
         pk = (C.c_ubyte * 4096)()
-        nb = C.c_int(0)
-        n = self.l.hxo_encode_frame_packet(self.h, frame.ctypes.data, self.out, pk, C.byref(nb))
-        return bytes(self.out[:n]), bytes(pk[:nb.value])
+        nb = (C.c_int * 2)()
+        n = self.l.hxo_encode_frame_packet(self.h, frame.ctypes.data, self.out, pk, nb)
+        self.packet_sizes = (nb[0], nb[1])      # MPEG-2: two single-granule packets back to back
+        return bytes(self.out[:n]), bytes(pk[:nb[0] + nb[1]])
 
     def __del__(self):
         try:
@@ -158,7 +159,8 @@ class RefEncoder:
         pk = (C.c_ubyte * 4096)()
         nb = (C.c_int * 2)()
         n = self.r.ref_encode_packet(self.h, frame.ctypes.data, self.out, pk, nb)
-        return bytes(self.out[:n]), bytes(pk[:nb[0]])
+        self.packet_sizes = (nb[0], nb[1])
+        return bytes(self.out[:n]), bytes(pk[:nb[0] + nb[1]])
 
     def dump(self):
         d = RefDump()

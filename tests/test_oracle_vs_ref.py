@@ -120,6 +120,57 @@ def test_packet_variant_byte_identical(kw):
         a = r.encode_packet(pcm[f * 1152:(f + 1) * 1152])
         b = o.encode_packet(pcm[f * 1152:(f + 1) * 1152])
         assert a == b and len(a[1]) >= 36, "frame %d" % f
+        assert r.packet_sizes == o.packet_sizes and r.packet_sizes[1] == 0
+
+
+LSF_CASES = [
+    # MPEG-2 LSF rates: one granule per frame, 8-bit main_data_begin, 9-bit scalefac_compress
+    ("lsf_cbr64_22k", dict(bitrate=32, samprate=22050), 22050, 0.7),
+    ("lsf_cbr64_22k_long", dict(bitrate=32, samprate=22050, short_block_threshold=99999), 22050, 0.7),
+    ("lsf_cbr64_24k", dict(bitrate=32, samprate=24000), 24000, 0.7),
+    ("lsf_cbr48_16k", dict(bitrate=24, samprate=16000), 16000, 0.7),
+    ("lsf_cbr160_24k", dict(bitrate=80, samprate=24000), 24000, 0.3),
+    ("lsf_cbr64_lr", dict(bitrate=32, samprate=22050, mode=0), 22050, 0.3),
+    ("lsf_vbr50_22k", dict(samprate=22050), 22050, 0.7),
+    ("lsf_vbr0_16k", dict(samprate=16000, vbr_mnr=0), 16000, 0.7),
+    ("lsf_vbr150_24k", dict(samprate=24000, vbr_mnr=150), 24000, 0.7),
+    ("lsf_dc", dict(bitrate=32, samprate=22050, filter_select=1), 22050, 0.7),
+    ("lsf_mono_cbr32_22k", dict(bitrate=32, samprate=22050, mode=3), 22050, 0.7),
+    ("lsf_mono_vbr_16k", dict(samprate=16000, mode=3), 16000, 0.7),
+    ("lsf_mono_cbr8_16k", dict(bitrate=8, samprate=16000, mode=3), 16000, 0.7),
+]
+
+
+@pytest.mark.parametrize("name,kw,sr,rho", LSF_CASES, ids=[c[0] for c in LSF_CASES])
+@pytest.mark.parametrize("bursts", [False, True], ids=["steady", "bursts"])
+def test_mpeg2_streams_byte_identical(name, kw, sr, rho, bursts):
+    pcm = synth.stream_pcm(17, 100, sr=sr, rho=rho, bursts=bursts)
+    r = O.RefEncoder(O.default_control(**kw))
+    o = O.OracleEncoder(O.default_control(**kw))
+    if kw.get("mode") == 3:
+        pcm = pcm[:, 0].copy()
+        a = b"".join(r.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(100))
+        b = b"".join(o.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(100))
+    else:
+        a = O.encode_stream(r, pcm)
+        b = O.encode_stream(o, pcm)
+    assert len(a) > 0 and a == b
+
+
+@pytest.mark.parametrize("kw", [dict(bitrate=32, samprate=22050), dict(samprate=24000, vbr_mnr=80), dict(bitrate=32, samprate=16000, mode=3)],
+                         ids=["cbr64_22k", "vbr80_24k", "mono_cbr32_16k"])
+def test_mpeg2_packet_variant_byte_identical(kw):
+    """L3_audio_encode_MPEG2Packet / _vbr_MPEG2Packet: two packets per call, nbytes_out[0..1]"""
+    nfr = 50
+    pcm = synth.stream_pcm(23, nfr, sr=kw["samprate"], bursts=True).astype(np.float32)
+    if kw.get("mode") == 3:
+        pcm = pcm[:, 0].copy()
+    r = O.RefEncoder(O.default_control(**kw), s16=False)
+    o = O.OracleEncoder(O.default_control(**kw))
+    for f in range(nfr):
+        a = r.encode_packet(pcm[f * 1152:(f + 1) * 1152])
+        b = o.encode_packet(pcm[f * 1152:(f + 1) * 1152])
+        assert a == b and r.packet_sizes == o.packet_sizes and min(r.packet_sizes) >= 13, "frame %d" % f
 
 
 def test_carried_state_matches_every_frame():
