@@ -229,12 +229,13 @@ class Mp3Enc:
         return x.in_bytes, bytes(self._out[: x.out_bytes])
 
     def L3_audio_encode_Packet(self, pcm_f32):
-        """-> (in_bytes, bitstream bytes, packet bytes)"""
+        """-> (in_bytes, bitstream bytes, packet bytes); self.packet_sizes = nbytes_out[2] (MPEG-2: two packets)"""
         pcm = np.ascontiguousarray(pcm_f32, dtype=np.float32)
         pk = (C.c_ubyte * 4096)()
         nb = (C.c_int * 2)()
         x = lib().hx_enc_L3_audio_encode_Packet(self.h, pcm.ctypes.data, self._out, pk, nb)
-        return x.in_bytes, bytes(self._out[: x.out_bytes]), bytes(pk[: nb[0]])
+        self.packet_sizes = (nb[0], nb[1])
+        return x.in_bytes, bytes(self._out[: x.out_bytes]), bytes(pk[: nb[0] + nb[1]])
 
     def MP3_audio_encode(self, pcm_i16):
         pcm = np.ascontiguousarray(pcm_i16, dtype=np.int16)

@@ -16,9 +16,9 @@
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
                             const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan);
 __global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S, int nchan);
-__global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total);
+__global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total, int lsf);
 __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
-                             int *dbg_metric, int NG, int total);
+                             int *dbg_metric, int NG, int total, int lsf);
 __global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
 __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                        float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
@@ -30,6 +30,7 @@ struct AllocArgs {
     unsigned char *packet; long long packet_stride; int *packet_bytes; int *frame_stats;
 };
 __global__ void k_alloc(AllocArgs a);
+__global__ void k_alloc_lsf(AllocArgs a);
 
 static thread_local std::string g_err;
 static void set_err(const char *fmt, const char *a = "")
@@ -54,6 +55,7 @@ struct hx_batch {
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
     bool any_dc = false;
     int nchan = 2;                      // channels of the PCM input, the same for every stream of the batch
+    int lsf = 0;                        // 1: an MPEG-2 LSF batch (16 / 22.05 / 24 kHz): every 1152-sample block yields two frames
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
     unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
     HxFrameDebug *d_dbg = nullptr;
@@ -109,10 +111,11 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         for (size_t i = 0; i < seen.size(); i++) if (memcmp(&seen[i], c, sizeof(HxControl)) == 0) { k = (int) i; break; }
         if (k < 0) {
             HxParams p;
-            if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: MPEG-1 mono / stereo / joint stereo without intensity only)"); delete b; return nullptr; }
+            if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: mono / stereo / joint stereo without intensity only)"); delete b; return nullptr; }
             if (p.filter_dc) b->any_dc = true;
-            if (b->params.empty()) b->nchan = p.nchan;
+            if (b->params.empty()) { b->nchan = p.nchan; b->lsf = p.h_id ? 0 : 1; }
             else if (p.nchan != b->nchan) { set_err("mono and stereo streams cannot share a batch (the PCM layout differs)"); delete b; return nullptr; }
+            else if ((p.h_id ? 0 : 1) != b->lsf) { set_err("MPEG-1 and MPEG-2 sample rates cannot share a batch (frames per call differ)"); delete b; return nullptr; }
             seen.push_back(*c);
             b->params.push_back(p);
             k = (int) seen.size() - 1;
@@ -162,7 +165,7 @@ extern "C" long long hx_batch_out_stride(const hx_batch *b, int nframes)
         int fb = p.vbr_flag ? p.vbr_framebytes[p.ivbr_max] : p.framebytes + 1;
         if (fb > maxframe) maxframe = fb;
     }
-    long long n = (long long) (nframes + 2) * maxframe + 4096;
+    long long n = (long long) ((b->lsf ? 2 : 1) * nframes + 2) * maxframe + 4096;
     return (n + 255) & ~255LL;
 }
 
@@ -202,10 +205,10 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     if (b->any_dc) hipLaunchKernelGGL(k_dcfilter, dim3((b->nchan * S + 63) / 64), dim3(64), 0, q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S, b->nchan);
     hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan);
     int tot = S * 2 * NG * 9;
-    hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot);
+    hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot, b->lsf);
     tot = S * NG;
     hipLaunchKernelGGL(k_attack_flg, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
-                       b->debug ? b->d_dbgmetric : nullptr, NG, tot);
+                       b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
     hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, b->d_bt, b->d_btprev, NG, S);
     long long units = (long long) S * NG * 2;
     hipLaunchKernelGGL(k_spec, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_gt, b->d_bt, b->d_xr,
@@ -219,7 +222,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, q));
-    hipLaunchKernelGGL(k_alloc, dim3(S), dim3(64), 0, q, a);
+    if (b->lsf) hipLaunchKernelGGL(k_alloc_lsf, dim3(S), dim3(64), 0, q, a);
+    else hipLaunchKernelGGL(k_alloc, dim3(S), dim3(64), 0, q, a);
     HIPCHK(hipEventRecord(e1, q));
     b->pending.push_back({e0, e1});
     hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
@@ -453,7 +457,7 @@ static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned cha
         memcpy(bs_out, e->outbuf.data(), nb);
         x.out_bytes = nb;
         e->bytes += nb;
-        e->ave = e->ave + ((((nb << 8) - e->ave)) >> 7);
+        e->ave = e->ave + ((((nb << 8) - e->ave)) >> (e->p.h_id ? 7 : 6));    // mp3enc.cpp:2328 / :2589
         e->frames = (unsigned) hx_batch_frames_bytes(e->b, 0).a;
     }
     return x;
@@ -467,7 +471,8 @@ extern "C" HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigne
 
 // CMp3Enc::L3_audio_encode_Packet / MP3_audio_encode_Packet (pub/mp3enc.h:110-131): the normal
 // bitstream in bs_out (may be NULL) plus this call's frame as a self-contained packet
-// (nbytes_out[0] bytes, nbytes_out[1] = 0); packet may be NULL.
+// (nbytes_out[0] bytes, nbytes_out[1] = 0; at the MPEG-2 rates two packets, nbytes_out[0] then
+// nbytes_out[1] bytes); packet may be NULL.
 extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out);
 static HX_IN_OUT encode_packet(hx_enc *e, const void *pcm, int mp3_entry, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2])
 {
@@ -475,16 +480,16 @@ static HX_IN_OUT encode_packet(hx_enc *e, const void *pcm, int mp3_entry, unsign
     if (!bs_out) { scratch.resize(e->outbuf.size()); bs_out = scratch.data(); }
     if (packet) {
         hipSetDevice(e->device);
-        if (!e->d_packet) { hipMalloc((void **) &e->d_packet, 2048); hipMalloc((void **) &e->d_packet_bytes, sizeof(int)); }
-        hx_batch_packet_buffers(e->b, e->d_packet, 2048, e->d_packet_bytes);
+        if (!e->d_packet) { hipMalloc((void **) &e->d_packet, 4096); hipMalloc((void **) &e->d_packet_bytes, 2 * sizeof(int)); }
+        hx_batch_packet_buffers(e->b, e->d_packet, 4096, e->d_packet_bytes);
     }
     HX_IN_OUT x = mp3_entry ? hx_enc_MP3_audio_encode(e, (const unsigned char *) pcm, bs_out) : hx_enc_L3_audio_encode(e, (const float *) pcm, bs_out);
     if (packet) {
-        int n = 0;
-        hipMemcpy(&n, e->d_packet_bytes, sizeof(int), hipMemcpyDeviceToHost);
-        hipMemcpy(packet, e->d_packet, (size_t) n, hipMemcpyDeviceToHost);
-        nbytes_out[0] = n;
-        nbytes_out[1] = 0;
+        int n[2] = {0, 0};      // an MPEG-2 call returns two single-granule packets back to back (mp3enc.cpp:3363)
+        hipMemcpy(n, e->d_packet_bytes, 2 * sizeof(int), hipMemcpyDeviceToHost);
+        hipMemcpy(packet, e->d_packet, (size_t) (n[0] + n[1]), hipMemcpyDeviceToHost);
+        nbytes_out[0] = n[0];
+        nbytes_out[1] = n[1];
         hx_batch_packet_buffers(e->b, nullptr, 0, nullptr);
     }
     return x;
@@ -556,7 +561,8 @@ extern "C" HX_INT_PAIR hx_enc_get_frames_bytes(hx_enc *e) { HX_INT_PAIR r = {(in
 extern "C" float hx_enc_get_bitrate_float(hx_enc *e)
 {
     if (e->frames <= 0) return 0.0f;
-    return ((0.001f * 8.0f) * e->bytes * e->p.samprate / (1152.0f * e->frames));
+    const float samples = e->p.h_id ? 1152.0f : 576.0f;        // per frame: MPEG-1 / MPEG-2 (mp3enc.cpp:3456-3462)
+    return ((0.001f * 8.0f) * e->bytes * e->p.samprate / (samples * e->frames));
 }
 extern "C" int hx_enc_get_bitrate(hx_enc *e) { return (int) (hx_enc_get_bitrate_float(e) + 0.5f); }
 extern "C" float hx_enc_get_bitrate2_float(hx_enc *e)

@@ -173,17 +173,19 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     }
 }
 
-// energies of subbands 4..17 per slot pair, as mB.  eng index g <-> subband slot g + 2.
+// energies of subbands 4..17 (MPEG-2 LSF rates: 8..27, detect.c:147-196) per slot pair, as mB.
+// eng index g <-> subband slot g + 2.
 __global__ void k_attack_eng(const float *__restrict__ sb, const HxGlobalTabs *__restrict__ gt,
-                             int *__restrict__ eng, int NG, int SG, int total)
+                             int *__restrict__ eng, int NG, int SG, int total, int lsf)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
     int k = id % 9, r = id / 9;
     int g = r % NG, sc = r / NG;
-    const float *y = sb + ((long long) sc * SG + (g + 2)) * 576 + 18 * 4 + 2 * k;
+    const int sb0 = lsf ? 8 : 4, nsbb = lsf ? 20 : 14;
+    const float *y = sb + ((long long) sc * SG + (g + 2)) * 576 + 18 * sb0 + 2 * k;
     float sum = 7.0e4f;
-    for (int i = 0; i < 14; i++, y += 18) {
+    for (int i = 0; i < nsbb; i++, y += 18) {
         float x = y[0] * y[0]; sum += x;
         x = y[1] * y[1]; sum += x;
     }
@@ -191,7 +193,8 @@ __global__ void k_attack_eng(const float *__restrict__ sb, const HxGlobalTabs *_
 }
 
 // attack metric of one channel at coded step g, for short_flag_prev = 0 and 1
-__device__ __forceinline__ void attack_metric(const int *hist, const int *eng, int g, int *m0, int *m1)
+// (the MPEG-2 detector looks back four values instead of six, detect.c:205-226)
+__device__ __forceinline__ void attack_metric(const int *hist, const int *eng, int g, int *m0, int *m1, int lsf)
 {
     // virtual buffer A: 32 history values followed by 9 new values per step
     int w[32];
@@ -203,7 +206,7 @@ __device__ __forceinline__ void attack_metric(const int *hist, const int *eng, i
     int r0 = 0, r1 = 0;
 #pragma unroll
     for (int j = 17; j < 29; j++) {
-        int a0 = max(w[j - 6], w[j - 7]);
+        int a0 = lsf ? -0x7fffffff : max(w[j - 6], w[j - 7]);
         int a1 = max(w[j - 4], w[j - 5]);
         int a2 = max(w[j - 2], w[j - 3]);
         a1 = max(a1, a0);
@@ -218,7 +221,7 @@ __device__ __forceinline__ void attack_metric(const int *hist, const int *eng, i
 
 __global__ void k_attack_flg(const HxStream *__restrict__ st, const HxParams *__restrict__ prm,
                              const int *__restrict__ eng, unsigned char *__restrict__ flg,
-                             int *__restrict__ dbg_metric, int NG, int total)
+                             int *__restrict__ dbg_metric, int NG, int total, int lsf)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
@@ -226,8 +229,8 @@ __global__ void k_attack_flg(const HxStream *__restrict__ st, const HxParams *__
     const HxStream *ss = st + s;
     int thr = prm[ss->cls].short_block_threshold;
     int a0, a1, b0, b1;
-    attack_metric(ss->attack_hist[0], eng + (long long) (s * 2 + 0) * NG * 9, g, &a0, &a1);
-    attack_metric(ss->attack_hist[1], eng + (long long) (s * 2 + 1) * NG * 9, g, &b0, &b1);
+    attack_metric(ss->attack_hist[0], eng + (long long) (s * 2 + 0) * NG * 9, g, &a0, &a1, lsf);
+    attack_metric(ss->attack_hist[1], eng + (long long) (s * 2 + 1) * NG * 9, g, &b0, &b1, lsf);
     int f0 = (a0 > thr) | (b0 > thr), f1 = (a1 > thr) | (b1 > thr);
     flg[id] = (unsigned char) (f0 | (f1 << 1));
     if (dbg_metric) { dbg_metric[id * 2] = a0; dbg_metric[id * 2 + 1] = b0; }

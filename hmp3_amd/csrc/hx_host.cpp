@@ -16,16 +16,37 @@
 
 static float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-// ISO 11172-3 Table B.8, MPEG-1 (44.1, 48, 32 kHz)
-static const short sfb_long[3][23] = {
+// Scalefactor band edges.  Rows 0..2: ISO 11172-3 Table B.8, MPEG-1 (44.1, 48, 32 kHz); rows 3..5:
+// ISO 13818-3, MPEG-2 LSF (22.05, 24, 16 kHz) as the reference carries them (l3init.c:56-99).
+// Row = HxParams::tix = sr_index + 3 * (1 - h_id).
+static const short sfb_long[6][23] = {
     {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 52, 62, 74, 90, 110, 134, 162, 196, 238, 288, 342, 418, 576},
     {0, 4, 8, 12, 16, 20, 24, 30, 36, 42, 50, 60, 72, 88, 106, 128, 156, 190, 230, 276, 330, 384, 576},
-    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 54, 66, 82, 102, 126, 156, 194, 240, 296, 364, 448, 550, 576}};
-static const short sfb_short[3][14] = {
+    {0, 4, 8, 12, 16, 20, 24, 30, 36, 44, 54, 66, 82, 102, 126, 156, 194, 240, 296, 364, 448, 550, 576},
+    {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576},
+    {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 114, 136, 162, 194, 232, 278, 332, 394, 464, 540, 576},
+    {0, 6, 12, 18, 24, 30, 36, 44, 54, 66, 80, 96, 116, 140, 168, 200, 238, 284, 336, 396, 464, 522, 576}};
+static const short sfb_short[6][14] = {
     {0, 4, 8, 12, 16, 22, 30, 40, 52, 66, 84, 106, 136, 192},
     {0, 4, 8, 12, 16, 22, 28, 38, 50, 64, 80, 100, 126, 192},
-    {0, 4, 8, 12, 16, 22, 30, 42, 58, 78, 104, 138, 180, 192}};
+    {0, 4, 8, 12, 16, 22, 30, 42, 58, 78, 104, 138, 180, 192},
+    {0, 4, 8, 12, 18, 24, 32, 42, 56, 74, 100, 132, 174, 192},
+    {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 136, 180, 192},
+    {0, 4, 8, 12, 18, 26, 36, 48, 62, 80, 104, 134, 174, 192}};
 static const int br_mpeg1_l3[16] = {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, -1};
+static const int br_mpeg2_l3[16] = {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, -1};
+
+// frequency of the scalefactor band edge nearest to freq (l3init.c:148-172)
+static int nearest_sf_band_freq(int tix, int samprate, int freq)
+{
+    int fout = freq, deltamin = 999999;
+    float a = samprate / (2.0f * 576.0f);
+    for (int i = 0; i < 21; i++) {
+        int f = (int) (a * sfb_long[tix][i + 1] + 0.5f), delta = abs(f - freq);
+        if (delta < deltamin) { deltamin = delta; fout = f; }
+    }
+    return fout;
+}
 
 void hx_host_default_control(HxControl *ec)
 {
@@ -249,7 +270,7 @@ static void psy_short_tables(HxParams *p)
     float x = 0.5f * p->samprate / 192;
     for (i = 0; i < 31; i++) {
         float freq = x * 0.5f * (part[i] + part[i + 1]);
-        snr_factor[i] = (float) (0.7 * pow(10.0, -0.1 * interp(dbsnr, freq)));
+        snr_factor[i] = (float) ((p->h_id ? 0.7 : 2.8) * pow(10.0, -0.1 * interp(dbsnr, freq)));     // amodini2.c:678-690
         bval[i] = f_to_bark(freq);
     }
     snr_factor[i] = 1.0f;
@@ -282,7 +303,7 @@ static void psy_short_tables(HxParams *p)
 }
 
 // Returns 0 when the configuration is outside what the MI355X path implements (the reference
-// would run MPEG-2, mono, dual-channel or intensity stereo there) or when the reference itself
+// would run dual-channel or intensity stereo there) or when the reference itself
 // rejects it (mp3enc.cpp:346-351,388); 9216 (bytes of float PCM per frame) otherwise.
 int hx_resolve(const HxControl *ec_arg, HxParams *p)
 {
@@ -314,42 +335,49 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
 
     int k = 0, dmin = 99999;
     for (int i = 0; i < 8; i++) { int d = abs(ec.samprate - sr_all[i]); if (d < dmin) { dmin = d; k = i; } }
-    if ((k >> 2) != 1) return 0;                    // MPEG-2 LSF rates: not on this path
+    if (sr_all[k] == 1) return 0;
+    const int h_id = k >> 2;                        // 1 = MPEG-1, 0 = MPEG-2 LSF (16 / 22.05 / 24 kHz)
+    p->h_id = h_id;
     p->sr_index = k & 3;
+    p->tix = p->sr_index + 3 * (1 - h_id);
+    const int *br_tab = h_id ? br_mpeg1_l3 : br_mpeg2_l3;
     if (ec.mode == 2) return 0;                     // dual channel (legacy allocator): not on this path
     p->h_mode = ec.mode;
     p->nchan = (ec.mode == 3) ? 1 : 2;
     int mode_ext = (p->h_mode == 1) ? ec.nsbstereo / 4 - 1 : 0;
-    mode_ext = MN(MX(mode_ext, 0), 3);
+    if (mode_ext < 0) mode_ext = h_id ? 0 : 1;      // setup.c:234-239 (every frame rewrites these two bits)
+    mode_ext = MN(mode_ext, 3);
     int bitrate = MX(ec.bitrate, 8) * p->nchan;     // per-channel request; a mono frame carries one channel (setup.c:254-258)
-    if (bitrate > 320) bitrate = 320;
+    if (bitrate > (h_id ? 320 : 160)) bitrate = h_id ? 320 : 160;
     int br_index = 0;
-    for (int i = 1; br_mpeg1_l3[i] >= 0; i++) if (br_mpeg1_l3[i] == bitrate) br_index = i;
+    for (int i = 1; br_tab[i] >= 0; i++) if (br_tab[i] == bitrate) br_index = i;
     p->totbitrate = bitrate;
     HxMpegHead *h = &p->head_info;
-    h->sync = 1; h->id = 1; h->option = 1; h->prot = 1; h->br_index = br_index; h->sr_index = p->sr_index;
+    h->sync = 1; h->id = h_id; h->option = 1; h->prot = 1; h->br_index = br_index; h->sr_index = p->sr_index;
     h->mode = p->h_mode; h->mode_ext = mode_ext; h->cr = ec.cr_bit; h->original = ec.original;
     p->head[0] = 0xFF;
-    p->head[1] = 0xFB;
+    p->head[1] = (unsigned char) (0xF3 | (h_id << 3));
     p->head[2] = (unsigned char) ((br_index << 4) | (p->sr_index << 2));
     p->head[3] = (unsigned char) ((p->h_mode << 6) | (mode_ext << 4) | (ec.cr_bit << 3) | (ec.original << 2));
 
-    p->nband = sfb_long[p->sr_index][21];
+    p->nband = sfb_long[p->tix][21];
     p->nsb = (p->nband + 17) / 18;
-    int nsbstereo = 12 * p->totbitrate / 32 - 20;
+    int nsbstereo = h_id ? 12 * p->totbitrate / 32 - 20 : 7 * p->totbitrate / 16 - 7;     // mp3enc.cpp:406-422
     nsbstereo = MX(MN(nsbstereo, 32), 3);
-    if (p->totbitrate >= 96) nsbstereo = 32;
+    if (p->totbitrate >= (h_id ? 96 : 48)) nsbstereo = 32;
     if (ec.vbr_flag) nsbstereo = 32;
     if (ec.nsbstereo > 0) nsbstereo = MN(MX(ec.nsbstereo, 3), 32);
     if (nsbstereo > p->nsb) nsbstereo = p->nsb;
-    p->samprate = sr_all[4 + p->sr_index];
+    p->samprate = sr_all[4 * h_id + p->sr_index];
     p->divisor = p->samprate;
-    p->framebytes = 144000 * p->totbitrate / p->divisor;
-    p->remainder = (144000 * p->totbitrate) % p->divisor;
-    p->side_bytes = (p->h_mode == 3) ? 17 : 32;
+    // an MPEG-2 frame is one granule: half the bytes, and the side info shrinks to 17 / 9 (mp3enc.cpp:447-481)
+    const int fcoef = h_id ? 144000 : 72000;
+    p->framebytes = fcoef * p->totbitrate / p->divisor;
+    p->remainder = (fcoef * p->totbitrate) % p->divisor;
+    p->side_bytes = h_id ? ((p->h_mode == 3) ? 17 : 32) : ((p->h_mode == 3) ? 9 : 17);
     p->main_framebytes = p->framebytes - 4 - p->side_bytes;
     p->sf_bit_max = 3 * (6 * 4 + 6 * 3);
-    p->AveTargetBits = 8 * p->main_framebytes / 2;          // bits per granule ...
+    p->AveTargetBits = 8 * p->main_framebytes / (h_id ? 2 : 1);     // bits per granule ...
     if (p->h_mode != 3) p->AveTargetBits >>= 1;             // ... and per channel
     p->AveTargetBits -= p->sf_bit_max;
 
@@ -365,15 +393,24 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     }
     int nsb_limit_user = MN(u1, u2);
     if (ec.vbr_flag) {
-        freq_limit = 12000 + 80 * ec.vbr_mnr;
-        if (ec.vbr_mnr <= 5) freq_limit = 12000;
+        freq_limit = h_id ? 12000 + 80 * ec.vbr_mnr : 7500 + 50 * ec.vbr_mnr;      // mp3enc.cpp:505-533
+        if (ec.vbr_mnr <= 5) freq_limit = h_id ? 12000 : 7500;
         freq_limit = MN(freq_limit, ((int) ((0.96f * 0.5f) * p->samprate)));
     } else {
         static const float factor[4] = {1.1f, 1.333f, 1.0f, 1.0f};
         float chan_bitrate = (float) p->totbitrate;
         if (p->h_mode != 3) chan_bitrate = (float) (0.5 * chan_bitrate);
         chan_bitrate = factor[p->h_mode] * chan_bitrate;
-        freq_limit = (int) (187.97 * chan_bitrate);
+        if (p->samprate < 32000) {                  // calc_freq_limit_L3, low rates (mp3enc.cpp:899-935)
+            if (chan_bitrate <= 32.0f) freq_limit = (int) (752.0 + 203.0 * chan_bitrate);
+            else if (chan_bitrate <= 42.7f) freq_limit = (int) (-2967.0 + 327.0 * chan_bitrate);
+            else freq_limit = 11000;
+        } else freq_limit = (int) (187.97 * chan_bitrate);
+    }
+    if (h_id == 0) {                                // snap to a scalefactor band edge, then to a subband (mp3enc.cpp:526-545)
+        freq_limit = nearest_sf_band_freq(p->tix, p->samprate, freq_limit);
+        int tmp = (64 * freq_limit + (p->samprate / 2)) / p->samprate;
+        freq_limit = (tmp * p->samprate) / 64;
     }
     p->nsb_limit = nsb_user_flag ? nsb_limit_user : (64 * MX(freq_limit, 1000) + p->samprate / 2) / p->samprate;
     p->nsb_limit = MN(p->nsb, p->nsb_limit);
@@ -389,8 +426,8 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     p->filter_alpha = (float) (0.001 * 44100.0 / p->samprate);
     p->filter_dc = ec.filter_select > 1 ? 1 : ec.filter_select;
 
-    for (int i = 0; i < 22; i++) p->nBand_l_iso[i] = p->nBand_l[i] = sfb_long[p->sr_index][i + 1] - sfb_long[p->sr_index][i];
-    for (int i = 0; i < 13; i++) p->nBand_s[i] = sfb_short[p->sr_index][i + 1] - sfb_short[p->sr_index][i];
+    for (int i = 0; i < 22; i++) p->nBand_l_iso[i] = p->nBand_l[i] = sfb_long[p->tix][i + 1] - sfb_long[p->tix][i];
+    for (int i = 0; i < 13; i++) p->nBand_s[i] = sfb_short[p->tix][i + 1] - sfb_short[p->tix][i];
     transform_tables(p);
     psy_long_tables(p);
     psy_short_tables(p);
@@ -402,31 +439,33 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     p->vbr_flag = ec.vbr_flag;
     if (ec.vbr_flag) {                              // gen_vbr_table (mp3enc.cpp:964-1041)
         for (int i = 1; i < 15; i++) {
-            int mb = 144000 * br_mpeg1_l3[i] / p->samprate;
+            int mb = fcoef * br_tab[i] / p->samprate;
             p->vbr_framebytes[i] = mb;
             p->vbr_main_framebytes[i] = mb - 4 - p->side_bytes;
         }
         p->vbr_framebytes[15] = p->vbr_main_framebytes[15] = 9999999;
-        p->vbr_pool_target = 256;
+        const int pool_cap = h_id ? 511 : 255;      // main_data_begin is 9 bits in MPEG-1, 8 in MPEG-2
+        p->vbr_pool_target = (pool_cap + 1) >> 1;
         int i;
         for (i = 14; i >= 2; i--) {
-            if (p->nchan * ec.vbr_br_limit >= br_mpeg1_l3[i]) break;
-            p->vbr_pool_target = (p->vbr_pool_target + 511) >> 1;
+            if (p->nchan * ec.vbr_br_limit >= br_tab[i]) break;
+            p->vbr_pool_target = (p->vbr_pool_target + pool_cap) >> 1;
         }
         p->ivbr_max = i;
         p->ivbr_min = 1;
-        p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / (2 * p->nchan)) - p->sf_bit_max;
+        p->AveTargetBits = (8 * p->vbr_main_framebytes[p->ivbr_max] / ((h_id ? 2 : 1) * p->nchan)) - p->sf_bit_max;
         p->initialMNR = MN(MX(10 * ec.vbr_mnr, 210), 1500);
     } else {
-        p->initialMNR = MN(MX(125 * (p->totbitrate / p->nchan - 32) / 8, 0), 1000);
+        const int tmp = p->totbitrate / p->nchan;
+        p->initialMNR = MN(MX(h_id ? 125 * (tmp - 32) / 8 : 10 * ((30 * tmp) / 8 - 70), 0), 1000);
     }
     ec.vbr_delta_mnr = MX(MN(ec.vbr_delta_mnr, 50), -40);
     for (int i = 0; i < 21; i++) ec.mnr_adjust[i] = MX(MN(ec.mnr_adjust[i], 200), -200);
     p->hf_flag = ec.hf_flag;
     p->test1 = ec.test1 < 0 ? 6 : ec.test1;
 
-    p->nsf3[0] = p->nsf2[0] = p->nsf[0] = sfbl_limit(p->sr_index, p->band_limit);
-    p->nsf3[1] = p->nsf2[1] = p->nsf[1] = sfbl_limit(p->sr_index, p->band_limit_stereo);
+    p->nsf3[0] = p->nsf2[0] = p->nsf[0] = sfbl_limit(p->tix, p->band_limit);
+    p->nsf3[1] = p->nsf2[1] = p->nsf[1] = sfbl_limit(p->tix, p->band_limit_stereo);
     if (p->hf_flag) { p->nsf2[0] = 22; p->nBand_l[21] = 100; }
     if (p->hf_flag & 2) { p->nsf3[0] = 22; p->nsf3[1] = 22; }
     k = 0;
@@ -438,7 +477,7 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     p->startBand_s[13] = k;
     {   // CBitAlloShort::BitAlloInit (bitallos.cpp:128-200): limits arrive in long-block lines
         int bl = p->band_limit / 3 - 10, i;
-        for (i = 0; i < 14; i++) if (bl <= sfb_short[p->sr_index][i]) break;
+        for (i = 0; i < 14; i++) if (bl <= sfb_short[p->tix][i]) break;
         p->nsfs = i > 12 ? 12 : i;
         p->nbmax_s = p->startBand_s[p->nsfs];
         for (i = 0; i < 12; i++) p->look_log_cbwmb_s[i] = (int) (100.0f * (float) (10.0 * log10((double) (float) p->nBand_s[i])));
@@ -467,7 +506,7 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
         if (p->vbr_flag) for (int i = 11; i < 22; i++) p->taperNT[i] = MN(p->taperNT[i], p->initialMNR);
         for (int i = 0; i < 21; i++) p->taperNT[i] -= 10 * mnrGOLD[i];
     }
-    p->initialMNR += 10 * ec.vbr_delta_mnr;
+    p->initialMNR += 10 * ec.vbr_delta_mnr - (h_id ? 0 : 300);         // bitallo3.cpp:446-453
     for (int i = 0; i < 22; i++) if (p->nBand_l[i] != 0) p->rnBand_l[i] = (1.0f / p->nBand_l[i]);
 
     p->ec = ec;

@@ -35,6 +35,7 @@ struct HxParams {
     HxMpegHead head_info;
     unsigned char head[4];
     int totbitrate, samprate, sr_index, h_mode;
+    int h_id, tix;          // 1 = MPEG-1, 0 = MPEG-2 LSF (one granule per frame); band-table row
     int nband, nsb, nsb_limit, nsb_ms0, nsb_ms1, band_limit, band_limit_stereo;
     int framebytes, remainder, divisor, main_framebytes, side_bytes, sf_bit_max, AveTargetBits;
     int ms_flag, hf_flag, vbr_flag, short_block_threshold, filter_dc;

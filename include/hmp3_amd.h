@@ -69,7 +69,9 @@ void hx_enc_info_ec(hx_enc *e, HX_E_CONTROL *ec);           /* mp3enc.cpp:3491 *
 void hx_enc_info_head(hx_enc *e, HX_MPEG_HEAD *head);       /* mp3enc.cpp:3498 */
 /* pub/mp3enc.h:110-131 *_Packet: also return this call's frame as a self-contained ("reformatted")
    packet: header, side info with main_data_begin 0, unpadded main data; nbytes_out[0] = its size,
-   nbytes_out[1] = 0.  bs_out or packet may be NULL. */
+   nbytes_out[1] = 0.  At the MPEG-2 rates (16 / 22.05 / 24 kHz) a call yields two single-granule
+   frames (mp3enc.cpp:3301-3440): two packets back to back, nbytes_out[0] then nbytes_out[1] bytes.
+   bs_out or packet may be NULL. */
 HX_IN_OUT hx_enc_L3_audio_encode_Packet(hx_enc *e, const float *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 HX_IN_OUT hx_enc_MP3_audio_encode_Packet(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 void hx_enc_info_string(hx_enc *e, char *s);                /* mp3enc.cpp:3505, <= 80 chars */
@@ -98,8 +100,10 @@ int hx_batch_encode_f32_device(hx_batch *b, const float *d_pcm, int nframes, uns
 int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
                              long long out_stride, int *out_bytes);
 /* optional packet outputs of the batched calls: d_packet [nstreams][nframes][frame_stride] bytes,
-   d_packet_bytes [nstreams][nframes]; frame_stride >= 36 + largest main data of a frame (2048 is
-   always enough).  NULL switches them off.  Applies to the calls that follow. */
+   d_packet_bytes [nstreams][nframes][2] (the reference's nbytes_out[2] of every call: {size, 0},
+   or the sizes of the two back-to-back packets of an MPEG-2 call); frame_stride >= the packet
+   bytes of one call (4096 is always enough).  NULL switches them off.  Applies to the calls
+   that follow. */
 void hx_batch_packet_buffers(hx_batch *b, unsigned char *d_packet, long long frame_stride, int *d_packet_bytes);
 /* optional per-frame counters of the batched calls: d_stats [nstreams][nframes][2] = the stream's
    get_frames() / bytes emitted so far after each input frame, i.e. what a caller of the per-frame

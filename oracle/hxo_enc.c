@@ -120,7 +120,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     p->nchan = (ec.mode == 3) ? 1 : 2;
     mode_ext = 0;
     if (p->h_mode == 1) mode_ext = ec.nsbstereo / 4 - 1;
-    if (mode_ext < 0) mode_ext = 0;
+    if (mode_ext < 0) mode_ext = h_id ? 0 : 1;     /* setup.c:234-239 */
     if (mode_ext > 3) mode_ext = 3;
     bitrate = ec.bitrate;
     if (bitrate < 8) bitrate = 8;

@@ -160,6 +160,73 @@ def test_mono_batch_byte_identical_to_oracle(name):
     b.close()
 
 
+LSF = {
+    # MPEG-2 LSF rates: every 1152-sample block yields two single-granule frames
+    "lsf_cbr64_22k": dict(bitrate=32, samprate=22050),
+    "lsf_cbr64_22k_long": dict(bitrate=32, samprate=22050, short_block_threshold=99999),
+    "lsf_cbr64_24k_lr": dict(bitrate=32, samprate=24000, mode=0),
+    "lsf_cbr48_16k": dict(bitrate=24, samprate=16000),
+    "lsf_cbr160_24k": dict(bitrate=80, samprate=24000),
+    "lsf_vbr50_22k": dict(samprate=22050),
+    "lsf_vbr0_16k": dict(samprate=16000, vbr_mnr=0),
+    "lsf_vbr150_24k": dict(samprate=24000, vbr_mnr=150),
+    "lsf_cbr64_22k_dc": dict(bitrate=32, samprate=22050, filter_select=1),
+    "lsf_thr0_all_short": dict(bitrate=32, samprate=22050, short_block_threshold=0),
+    "lsf_mono_cbr32_22k": dict(bitrate=32, samprate=22050, mode=3),
+    "lsf_mono_vbr_16k": dict(samprate=16000, mode=3),
+    "lsf_mono_cbr8_16k": dict(bitrate=8, samprate=16000, mode=3),
+}
+
+
+@pytest.mark.parametrize("name", list(LSF))
+def test_mpeg2_batch_byte_identical_to_oracle(name):
+    kw = LSF[name]
+    sr = kw["samprate"]
+    mono = kw.get("mode") == 3
+    S, F = 8, 40
+    pcm = np.stack([synth.stream_pcm(700 + i, F, sr=sr, rho=RHOS[i % 4], bursts=wants_bursts(kw)) for i in range(S)])
+    if mono:
+        pcm = np.ascontiguousarray(pcm[:, :, 0])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    got = b.encode_host(pcm[:, :23 * 1152])
+    got2 = b.encode_host(pcm[:, 23 * 1152:])
+    assert b.status() == 0
+    for s in range(S):
+        assert got[s] + got2[s] == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    fb = [b.frames_bytes(s) for s in range(S)]
+    assert all(f[1] == len(got[i]) + len(got2[i]) for i, f in enumerate(fb))
+    assert all(2 * F - 34 <= f[0] <= 2 * F for f in fb)        # two frames per block, less what is still pending
+    b.close()
+
+
+def test_mpeg2_and_mpeg1_cannot_share_a_batch():
+    ecs = [api().default_control(bitrate=32, samprate=22050), api().default_control(bitrate=64)]
+    with pytest.raises(RuntimeError, match="cannot share a batch"):
+        api().Batch(ecs, nstreams=2, max_frames=4)
+
+
+@pytest.mark.parametrize("kw", [dict(bitrate=32, samprate=22050), dict(samprate=24000, vbr_mnr=80), dict(bitrate=32, samprate=16000, mode=3)],
+                         ids=["cbr64_22k", "vbr80_24k", "mono_cbr32_16k"])
+def test_mpeg2_packet_variant_matches_oracle(kw):
+    """L3_audio_encode_Packet at an MPEG-2 rate: two packets per call, nbytes_out[0..1]"""
+    nfr = 30
+    pcm = synth.stream_pcm(23, nfr, sr=kw["samprate"], bursts=True).astype(np.float32)
+    nin_want = 9216
+    if kw.get("mode") == 3:
+        pcm = np.ascontiguousarray(pcm[:, 0])
+        nin_want = 4608
+    e = api().Mp3Enc()
+    assert e.L3_audio_encode_init(api().default_control(**kw)) == nin_want
+    o = O.OracleEncoder(O.default_control(**kw))
+    for f in range(nfr):
+        nin, bs, pk = e.L3_audio_encode_Packet(pcm[f * 1152:(f + 1) * 1152])
+        want_bs, want_pk = o.encode_packet(pcm[f * 1152:(f + 1) * 1152])
+        assert nin == nin_want and bs == want_bs and pk == want_pk and e.packet_sizes == o.packet_sizes, "frame %d" % f
+    fr, by = e.L3_audio_encode_get_frames_bytes()
+    assert fr > 40 and abs(e.L3_audio_encode_get_bitrate_float() - 0.008 * by * kw["samprate"] / (576.0 * fr)) < 1e-2
+    e.close()
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""

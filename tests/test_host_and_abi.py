@@ -17,7 +17,11 @@ TABLES = ["psy_w", "psy_cnt", "psy_off", "psy_nsum", "psy_npart", "win", "csa", 
           "head", "ec", "scalars"]
 CONFIGS = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000),
            dict(samprate=32000, bitrate=64), dict(bitrate=96, mode=0), dict(bitrate=160), dict(vbr_mnr=120, quick=0),
-           dict(bitrate=64, mode=3), dict(mode=3, samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(bitrate=48, mode=3, samprate=32000)]
+           dict(bitrate=64, mode=3), dict(mode=3, samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(bitrate=48, mode=3, samprate=32000),
+           # MPEG-2 LSF rates
+           dict(bitrate=32, samprate=22050), dict(bitrate=24, samprate=16000), dict(bitrate=80, samprate=24000, mode=0),
+           dict(samprate=22050), dict(samprate=16000, vbr_mnr=0), dict(samprate=24000, vbr_mnr=150, vbr_br_limit=64),
+           dict(bitrate=8, samprate=16000, mode=3), dict(samprate=24000, mode=3, vbr_mnr=90)]
 
 
 def test_library_exports_every_declared_symbol():
@@ -58,7 +62,9 @@ def test_resolve_rejects_what_reference_rejects_and_out_of_scope():
     assert not ok(bitrate=64, layer=2)      # mp3enc.cpp:388
     assert ok(bitrate=64, mode=3)           # mono
     assert not ok(bitrate=64, mode=2)       # dual channel: documented out of scope
-    assert not ok(bitrate=32, samprate=22050)   # MPEG-2: documented out of scope
+    assert ok(bitrate=32, samprate=22050)       # MPEG-2 LSF
+    assert not ok(bitrate=8, samprate=16000)    # 16 kbps joint stereo turns intensity stereo on: documented out of scope
+    assert not ok(bitrate=64, samprate=5000)    # nearest entry of the rate table is a reserved index
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
