@@ -16,6 +16,9 @@
 // The gain search of all 42 bands advances in the same sweep.
 #include "hx_dev.h"
 
+#ifndef HX_LSF
+#define HX_LSF 0            // 1 when compiled as hx_alloc_lsf.hip: MPEG-2 LSF streams, one granule per frame
+#endif
 #define GMIN_OFFSET 70
 #define PART23 4021
 #define NB 22
@@ -34,7 +37,6 @@ struct AllocPrm {
     int nsfs, nbmax_s;
     struct { int npart; } psyS;
     int nchan, side_bytes;              // 1 / 17 for a mono stream (mode 3), 2 / 32 otherwise
-    int lsf;                            // MPEG-2 LSF stream: one granule per frame, side_bytes 9 / 17
 };
 
 struct alignas(16) AllocLds {
@@ -704,7 +706,7 @@ __device__ int scale_factors(AllocLds &L, const AllocPrm *p, int ms)
         else if (sp2 >= 0) { scale = 1; pre = 0; }
         else if (sp3 >= 0) { scale = 1; pre = 1; }
         else { scale = 1; pre = 0; }
-        if (p->lsf && sp0 < 0) { scale = 1; pre = 0; }     // fnc_sf_final_MPEG2 (bitallo3.cpp:1860-1888): no pre-emphasis
+        if (HX_LSF && sp0 < 0) { scale = 1; pre = 0; }     // fnc_sf_final_MPEG2 (bitallo3.cpp:1860-1888): no pre-emphasis
         if (band) {
             int noise = L.Noise[ch][i], nt = L.NT[ch][i];
             if (scale == 0) {
@@ -836,7 +838,7 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
         const bool bslow = mode == 1 && noise_band_needs_pow(L.look_34igain[GG - s], L.x34max[ch][i]);
         PROF_ACC(23);
         if (2 * nl <= 192) lucky_terms<3>(L, nl, ncmax, tf);
-        else if (2 * nl <= 256) lucky_terms<4>(L, nl, ncmax, tf);
+        else if (!HX_LSF || 2 * nl <= 256) lucky_terms<4>(L, nl, ncmax, tf);
         else lucky_terms<5>(L, nl, ncmax, tf);          // MPEG-2 band tables: sfb 0..12 end at line 136 / 140
         if (__any(bslow)) {     // a band reaches beyond the 256-entry table: rare, redo with pow()
             for (int c = 0; c < ncmax; c++)
