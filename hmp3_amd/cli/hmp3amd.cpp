@@ -5,7 +5,8 @@
 // test/tomp3.cpp:336-602 main, :645-1088 ff_encode): Xing/Info tag frame first, audio frames, four
 // frames of silence behind the input, drain until every submitted frame is out, then the tag is
 // completed in place.  Accepted: RIFF/WAVE, mono or stereo, 8/16/24/32-bit PCM or 32-bit float,
-// 32 / 44.1 / 48 kHz (what the GPU path encodes); everything else fails like an unsupported file.
+// 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz (what the GPU path encodes); everything else fails like an
+// unsupported file.
 // Batch mode encodes all files as one batch of streams (same channel count, same flags) and
 // reproduces per file exactly what the single-file loop writes.
 #include <cstdint>
@@ -95,8 +96,8 @@ bool load_input(const char *path, const Options &opt, Input *in)
     in->is_float = wi.type == 3;
     if ((wi.channels != 1 && wi.channels != 2) ||
         !((wi.type == 1 && (wi.bits == 8 || wi.bits == 16 || wi.bits == 24 || wi.bits == 32)) || (in->is_float && wi.bits == 32)) ||
-        (wi.rate != 32000 && wi.rate != 44100 && wi.rate != 48000)) {
-        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes mono or stereo 8/16/24/32-bit PCM or 32-bit float input at 32 / 44.1 / 48 kHz.\n");
+        (wi.rate != 32000 && wi.rate != 44100 && wi.rate != 48000 && wi.rate != 16000 && wi.rate != 22050 && wi.rate != 24000)) {
+        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes mono or stereo 8/16/24/32-bit PCM or 32-bit float input at 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz.\n");
         return false;
     }
     in->ec = opt.ec;
@@ -184,6 +185,7 @@ int encode_one_file(const char *fin, const char *fout, const Options &opt)
         const HX_INT_PAIR fb = hx_enc_get_frames_bytes(enc);
         tg.after_call((unsigned) fb.a, (unsigned) fb.b);
     }
+    if (in.ec_used.samprate < 32000) frames_expected *= 2;                          // MPEG-2: two frames per call (tomp3.cpp:1022)
     while (hx_enc_get_frames(enc) < frames_expected)                                // drain, tomp3.cpp:1020-1036
         emit(hx_enc_MP3_audio_encode(enc, zero.data(), bs.data()));
     const unsigned frames = hx_enc_get_frames(enc);
@@ -277,8 +279,9 @@ int encode_batch(const std::vector<const char *> &files, const Options &opt)
         tg.begin(in[i], opt.xing_flag);
         for (size_t u = 0; u < calls; u++) tg.after_call(fr[i][u], by[i][u]);
         size_t u = calls;                               // drain calls: while (get_frames() < frames_expected) encode silence
-        while (u < fr[i].size() && fr[i][u - 1] < calls) u++;
-        if (fr[i][u - 1] < calls) { fprintf(stderr, "\n %s: drain did not complete\n", files[2 * i]); rc = 1; }
+        const size_t expected = calls * (in[i].ec_used.samprate < 32000 ? 2 : 1);   // MPEG-2: two frames per call
+        while (u < fr[i].size() && fr[i][u - 1] < expected) u++;
+        if (fr[i][u - 1] < expected) { fprintf(stderr, "\n %s: drain did not complete\n", files[2 * i]); rc = 1; }
         const unsigned frames = fr[i][u - 1], nbytes = by[i][u - 1];
         tg.bytes(stream[i].data(), (int) nbytes);
         const uint64_t out_bytes = (uint64_t) tg.head_bytes + nbytes;

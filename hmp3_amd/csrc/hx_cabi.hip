@@ -515,7 +515,8 @@ extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, i
     if (mono_convert) ec2.mode = 3;
     if (!(source_bits == 8 || source_bits == 16 || source_bits == 24 || source_bits == 32)) { set_err("8, 16, 24 or 32-bit sources only"); return 0; }
     if (source_is_float && source_bits != 32) { set_err("float sources are 32-bit"); return 0; }
-    if (ec->samprate != 32000 && ec->samprate != 44100 && ec->samprate != 48000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
+    const int sr = ec->samprate;    // an MPEG rate is encoded as it is (mpeg_select 0 = track the input, mp3enc.cpp:2655-2808)
+    if (sr != 32000 && sr != 44100 && sr != 48000 && sr != 16000 && sr != 22050 && sr != 24000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
     int r = hx_enc_L3_audio_encode_init(e, &ec2);
     if (!r) return 0;
     e->src_bits = source_bits;

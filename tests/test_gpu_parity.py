@@ -78,7 +78,9 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
 @pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc",
                                   "cli_vbr50_s24_44k", "cli_cbr128_u8_44k", "cli_vbr50_s32_48k",
                                   "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k",
-                                  "cli_downmix_vbr50_s16_44k", "cli_downmix_cbr64_s24_48k"])
+                                  "cli_downmix_vbr50_s16_44k", "cli_downmix_cbr64_s24_48k",
+                                  "cli_lsf_cbr64_s16_22k", "cli_lsf_vbr50_f32_24k", "cli_lsf_mono_cbr24_s16_16k",
+                                  "cli_lsf_downmix_vbr80_s24_22k"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
     reference CLI (tests/golden/cli_*.mp3, tools/make_golden_cli.py)"""
@@ -112,23 +114,25 @@ def test_packet_variant_matches_oracle(kw):
     e.close()
 
 
-def test_cli_batch_mode_files_byte_identical_to_reference_cli(tmp_path):
-    """`hmp3amd -batch`: six files of different rates / sample formats / lengths encoded as one batch of streams;
+@pytest.mark.parametrize("which", ["mpeg1", "mpeg2"])
+def test_cli_batch_mode_files_byte_identical_to_reference_cli(tmp_path, which):
+    """`hmp3amd -batch`: files of different rates / sample formats / lengths encoded as one batch of streams;
     every output file must equal what the reference CLI writes for that input alone"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import make_golden_cli as M
+    inputs, bflags = (M.BATCH_INPUTS, M.BATCH_FLAGS) if which == "mpeg1" else (M.BATCH_LSF_INPUTS, M.BATCH_LSF_FLAGS)
     args = []
-    for name in M.BATCH_INPUTS:
+    for name in inputs:
         seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
         wav, mp3 = str(tmp_path / (name + ".wav")), str(tmp_path / (name + ".mp3"))
         M.write_wav(wav, M.case_pcm(name), sr, as_float)
         args += [wav, mp3]
-    r = subprocess.run([os.path.join(root, "hmp3_amd", "hmp3amd"), "-batch"] + args + M.BATCH_FLAGS, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([os.path.join(root, "hmp3_amd", "hmp3amd"), "-batch"] + args + bflags, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-400:]
-    for name in M.BATCH_INPUTS:
+    for name in inputs:
         got = open(str(tmp_path / (name + ".mp3")), "rb").read()
         assert got == open(os.path.join(GOLD, "batch_" + name[4:] + ".mp3"), "rb").read(), name
 

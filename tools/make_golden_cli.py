@@ -30,8 +30,13 @@ CASES = {
     # stereo file encoded as mono (-M3: down-mix)
     "cli_downmix_vbr50_s16_44k": (909, 60001, 44100, False, True, ["-M3"]),
     "cli_downmix_cbr64_s24_48k": (910, 50021, 48000, 24, False, ["-M3", "-B64"]),
+    # MPEG-2 LSF rates (one granule per frame, "Info"/"Xing" tag in the MPEG-2 layout)
+    "cli_lsf_cbr64_s16_22k": (911, 70001, 22050, False, True, ["-B32"]),
+    "cli_lsf_vbr50_f32_24k": (912, 60013, 24000, True, True, ["-V50"]),
+    "cli_lsf_mono_cbr24_s16_16k": (913, 50021, 16000, False, True, ["-B24"]),
+    "cli_lsf_downmix_vbr80_s24_22k": (914, 40009, 22050, 24, False, ["-M3", "-V80"]),
 }
-MONO = {"cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k"}
+MONO = {"cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k", "cli_lsf_mono_cbr24_s16_16k"}
 
 
 def write_wav(path, pcm_i16, sr, as_float):
@@ -79,6 +84,9 @@ def case_pcm(name):
 # batch mode: these stereo inputs are encoded together by `hmp3amd -batch ... -V60 -HF2`; the reference encodes them one by one
 BATCH_FLAGS = ["-V60", "-HF2"]
 BATCH_INPUTS = ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc", "cli_vbr50_s24_44k", "cli_cbr128_u8_44k", "cli_vbr50_s32_48k"]
+# the same for MPEG-2 rates (a batch holds MPEG-1 or MPEG-2 streams, not both)
+BATCH_LSF_FLAGS = ["-B40"]
+BATCH_LSF_INPUTS = ["cli_lsf_cbr64_s16_22k", "cli_lsf_vbr50_f32_24k"]
 
 
 if __name__ == "__main__":
@@ -103,5 +111,15 @@ if __name__ == "__main__":
             data = open(mp3, "rb").read()
         open(os.path.join(gold, "batch_" + name[4:] + ".mp3"), "wb").write(data)
         meta["batch_" + name[4:]] = {"bytes": len(data), "flags": BATCH_FLAGS}
+        print("batch_" + name[4:], len(data), "bytes")
+    for name in BATCH_LSF_INPUTS:
+        seed, nsamp, sr, as_float, bursts, flags = CASES[name]
+        with tempfile.TemporaryDirectory() as d:
+            wav, mp3 = os.path.join(d, "in.wav"), os.path.join(d, "out.mp3")
+            write_wav(wav, case_pcm(name), sr, as_float)
+            subprocess.run([ref, wav, mp3] + BATCH_LSF_FLAGS, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            data = open(mp3, "rb").read()
+        open(os.path.join(gold, "batch_" + name[4:] + ".mp3"), "wb").write(data)
+        meta["batch_" + name[4:]] = {"bytes": len(data), "flags": BATCH_LSF_FLAGS}
         print("batch_" + name[4:], len(data), "bytes")
     json.dump(meta, open(os.path.join(gold, "cli.json"), "w"), indent=1)
