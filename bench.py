@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
     ap.add_argument("--frames", type=int, default=256, help="frames per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="hx_batch_submit_s16_device / hx_batch_wait instead of plain calls")
     args = ap.parse_args()
 
     import torch
@@ -166,9 +167,15 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        batch.encode_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
+        # --pipeline: hx_batch_submit_s16_device lets the front end of step n+1 overlap step n's allocator kernel.
+        # Measured slower (the front-end kernels slow the allocator's waves more than the overlap saves), so off.
+        if args.pipeline:
+            batch.submit_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
+        else:
+            batch.encode_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
 
     def barrier():
+        batch.wait(stream)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

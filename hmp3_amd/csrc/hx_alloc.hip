@@ -100,6 +100,7 @@ struct alignas(16) AllocLds {
     unsigned short r_mf[32];            // pending frames: main-data bytes of the slot ...
     int r_off[32];                      // ... and offset of its header in the output buffer
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
+    int cmd, cmd_arg[3];                // work order for the helper wave (see HELPER_POST)
 #ifdef HX_PROFILE
     unsigned long long prof[64];
 #endif
@@ -119,14 +120,26 @@ struct alignas(16) AllocLds {
 // Rarely taken paths are kept out of line, away from the hot code: the kernel's instructions do not fit
 // the instruction cache that the waves of a CU share (DESIGN.md, K6 in detail).
 #define HX_COLD __attribute__((noinline, cold))
-#define LANE ((int) threadIdx.x)
+#define LANE ((int) threadIdx.x & 63)
+#define WAVE ((int) threadIdx.x >> 6)
 // The workgroup is a single wavefront, and a wave's LDS operations execute in issue order, so an
 // LDS hand-over between lanes only needs the compiler to keep the accesses in program order.
 // __syncthreads() would also drain every outstanding global load/store (s_waitcnt vmcnt(0)),
 // which costs a memory round trip per call in the frame-level code.  SYNC_G() is the full
 // barrier, used where lanes exchange data through global memory.
 #define SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-#define SYNC_G() __syncthreads()
+#define SYNC_G() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// A stream's workgroup is two wavefronts.  Wave 0 (the master) runs the encoder; wave 1 (the helper)
+// sleeps at the workgroup barrier until the master hands it one channel's share of a phase whose
+// channels are independent: HELPER_POST publishes the order in LDS and releases the helper,
+// HELPER_JOIN waits for it.  Everything else in this file is wave-local and never uses s_barrier.
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SWEEP_LOAD, HCMD_SWEEP };
+#define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmd = (c_); L.cmd_arg[0] = (a0_); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmd = (c_); L.cmd_arg[0] = (a0_); L.cmd_arg[1] = (a1_); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define HELPER_JOIN() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
 // ---------------------------------------------------------------------------------------
 // bit staging: OR an n-bit field (n <= 32) at absolute bit position pos
@@ -311,16 +324,39 @@ __device__ __forceinline__ bool noise_band_needs_pow(float igain, float x34max)
 
 // Line operands of the gain search, held in registers for a whole seek_actual call: lane l owns
 // lines l, l+64, ... l+512 of both channels (x, x^(3/4), and the line's sfb).
-struct SweepRegs { float x34[2][9], xr[2][9]; int bnd[9]; };
+// (one channel per wave: the master keeps channel 0, the helper wave channel 1)
+struct SweepRegs { float x34[9], xr[9]; int bnd[9]; };
 
-__device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R)
+__device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R, int ch)
 {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const int j = LANE + 64 * k;
         R.bnd[k] = L.band_of_line[j];
-        R.x34[0][k] = L.x34[0][j]; R.x34[1][k] = L.x34[1][j];
-        R.xr[0][k] = L.xr[0][j]; R.xr[1][k] = L.xr[1][j];
+        R.x34[k] = L.x34[ch][j];
+        R.xr[k] = L.xr[ch][j];
+    }
+}
+
+// Noise terms of one channel's lines [lo, nl) for the gain pairs published in L.gig / L.gg.
+// Chunks of three lines per lane (192 lines per chunk, chunks outside the evaluated range are
+// skipped): per line one gain-pair read, one table read, one store.  All loads of a chunk
+// come before its stores (an LDS store in between would pin the later loads behind it: the
+// compiler cannot tell the tables from the term buffer).  Lines of bands that are not being
+// evaluated get a meaningless term, which nobody reads - cheaper than predicating the store.
+__device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int ch, int lo, int nl)
+{
+#pragma unroll
+    for (int c3 = 0; c3 < 3; c3++) {
+        if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
+        float t[3];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int k = 3 * c3 + k3;
+            t[k3] = noise_term_fast(L, L.gig[ch][R.bnd[k]], L.gg[ch][R.bnd[k]], R.x34[k], R.xr[k]);
+        }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
     }
 }
 
@@ -346,27 +382,10 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     }
     SYNC();
     PROF_ACC(27);
-    // Chunks of three lines per lane (192 lines per chunk, chunks outside the evaluated range are
-    // skipped): per line one gain-pair read, one table read, one store.  All loads of a chunk
-    // come before its stores (an LDS store in between would pin the later loads behind it: the
-    // compiler cannot tell the tables from the term buffer).  Lines of bands that are not being
-    // evaluated get a meaningless term, which nobody reads - cheaper than predicating the store.
-#pragma unroll
-    for (int ch = 0; ch < 2; ch++) {
-        const int nl = min(ch ? nlines1 : nlines0, hi);
-#pragma unroll
-        for (int c3 = 0; c3 < 3; c3++) {
-            if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
-            float t[3];
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int k = 3 * c3 + k3;
-                t[k3] = noise_term_fast(L, L.gig[ch][R.bnd[k]], L.gg[ch][R.bnd[k]], R.x34[ch][k], R.xr[ch][k]);
-            }
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
-        }
-    }
+    const bool two = nlines1 > 0;       // channel 1's lines on the helper wave (a mono stream has none)
+    if (two) HELPER_POST2(HCMD_SWEEP, lo, min(nlines1, hi));
+    sweep_lines(L, R, 0, lo, min(nlines0, hi));
+    if (two) HELPER_JOIN();
     if (__any(bslow)) {     // some band reaches beyond the table: rare, redo its lines with pow()
         for (int ch = 0; ch < 2; ch++) {
             const int nl = min(ch ? nlines1 : nlines0, hi);
@@ -417,6 +436,30 @@ __device__ void adjust_nt(AllocLds &L, const AllocPrm *p)
     SYNC();
 }
 
+// x^(3/4) and band maxima of the first nl lines of channel c
+__device__ __forceinline__ void pow34_lines(AllocLds &L, int c, int nl)
+{
+#pragma unroll 1
+    for (int c3 = 0; c3 < 3; c3++) {
+        if (192 * c3 >= nl) continue;
+        float v[3];
+        int bnd[3];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int j = LANE + 64 * (3 * c3 + k3);
+            v[k3] = pow34(L, L.xr[c][j]);
+            bnd[k3] = L.band_of_line[j];
+        }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int j = LANE + 64 * (3 * c3 + k3);
+            const bool ok = j < nl;
+            *(ok ? &L.x34[c][j] : &L.dump[LANE]) = v[k3];
+            atomicMax(reinterpret_cast<int *>(ok ? &L.x34max[c][bnd[k3]] : &L.dump[LANE]), __float_as_int(v[k3]));
+        }
+    }
+}
+
 // x^(3/4) of the first nl lines, band maxima, gzero / gmin (reference bitallo3.cpp:878-896)
 __device__ void pow34_gzero(AllocLds &L, const AllocPrm *p, int nl0, int nl1, int nb0, int nb1)
 {
@@ -427,29 +470,9 @@ __device__ void pow34_gzero(AllocLds &L, const AllocPrm *p, int nl0, int nl1, in
     // (the reference's vect_fmax compares them as integers too, pow34.c:156-186)
     // Chunks of three lines per lane, all loads (line, tables) ahead of the stores; lines past
     // nl store into the per-lane sink so the chunk stays one basic block.
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-        const int nl = c ? nl1 : nl0;
-#pragma unroll 1
-        for (int c3 = 0; c3 < 3; c3++) {
-            if (192 * c3 >= nl) continue;
-            float v[3];
-            int bnd[3];
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int j = LANE + 64 * (3 * c3 + k3);
-                v[k3] = pow34(L, L.xr[c][j]);
-                bnd[k3] = L.band_of_line[j];
-            }
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int j = LANE + 64 * (3 * c3 + k3);
-                const bool ok = j < nl;
-                *(ok ? &L.x34[c][j] : &L.dump[LANE]) = v[k3];
-                atomicMax(reinterpret_cast<int *>(ok ? &L.x34max[c][bnd[k3]] : &L.dump[LANE]), __float_as_int(v[k3]));
-            }
-        }
-    }
+    if (nl1 > 0) HELPER_POST(HCMD_POW34, nl1);      // channel 1 on the helper wave
+    pow34_lines(L, 0, nl0);
+    if (nl1 > 0) HELPER_JOIN();
     SYNC();
     if (i < (ch ? nb1 : nb0)) {
         const float m = L.x34max[ch][i];
@@ -627,8 +650,10 @@ __device__ void seek_actual(AllocLds &L, const AllocPrm *p)
         else { smin = L.gzero[ch][i] + 5; tnmin = L.Noise0[ch][i]; }
     }
     SweepRegs R;
-    sweep_load(L, R);
     const int nl0 = p->nbmax[0], nl1 = p->nbmax[1];
+    if (nl1 > 0) HELPER_POST(HCMD_SWEEP_LOAD, 0);
+    sweep_load(L, R, 0);
+    if (nl1 > 0) HELPER_JOIN();
     SYNC();
     while (__any(mode != 0)) {
         PROF_CNT(20);
@@ -759,15 +784,16 @@ __device__ int scale_factors(AllocLds &L, const AllocPrm *p, int ms)
 // three candidates x NQ slots are independent LDS chains per block, all loads ahead of the
 // stores.  Terms of (candidate, band) pairs that are not being measured are computed and stored
 // too - nobody reads them, and it keeps the loop free of predicates.
+// A wave takes every other slot: w = 0 the even ones (master), w = 1 the odd ones (helper wave).
 template <int NQ>
-__device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, float *tf)
+__device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, float *tf, int w)
 {
     float sx34[NQ], sxr[NQ];
     int sg[NQ], ssd[NQ], stride[NQ];
     float *base[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const int t = LANE + 64 * q;
+        const int t = LANE + 64 * (2 * q + w);
         const bool ok = t < 2 * nl;
         const int cc = (ok && t >= nl) ? 1 : 0, j = ok ? t - (cc ? nl : 0) : 0;
         sx34[q] = L.x34[cc][j];
@@ -837,9 +863,16 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
         const int ncmax = hx_wave_max(nc);
         const bool bslow = mode == 1 && noise_band_needs_pow(L.look_34igain[GG - s], L.x34max[ch][i]);
         PROF_ACC(23);
-        if (2 * nl <= 192) lucky_terms<3>(L, nl, ncmax, tf);
-        else if (!HX_LSF || 2 * nl <= 256) lucky_terms<4>(L, nl, ncmax, tf);
-        else lucky_terms<5>(L, nl, ncmax, tf);          // MPEG-2 band tables: sfb 0..12 end at line 136 / 140
+        // slots of 64 flattened lines: 3 or 4 (MPEG-2 band tables: 5), shared between the two waves
+        const bool two = p->nchan == 2;
+        if (two) HELPER_POST2(HCMD_LUCKY, nl, ncmax);
+        if (!HX_LSF || 2 * nl <= 256) lucky_terms<2>(L, nl, ncmax, tf, 0);
+        else lucky_terms<3>(L, nl, ncmax, tf, 0);
+        if (two) HELPER_JOIN();
+        else {
+            if (!HX_LSF || 2 * nl <= 256) lucky_terms<2>(L, nl, ncmax, tf, 1);
+            else lucky_terms<3>(L, nl, ncmax, tf, 1);
+        }
         if (__any(bslow)) {     // a band reaches beyond the 256-entry table: rare, redo with pow()
             for (int c = 0; c < ncmax; c++)
                 for (int t = LANE; t < 2 * nl; t += 64) {
@@ -887,6 +920,39 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 }
 
 // reference bitallo3.cpp:1540-1585 with l3math.c:656-694: quantise every coded band
+// quantise channel c's lines with the band gains published in L.gig, track the band maxima
+__device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int opt, int c)
+{
+    const int nl = p->nbmax[c];
+#pragma unroll 1
+    for (int c3 = 0; c3 < 3; c3++) {
+        if (192 * c3 >= nl) continue;
+        int q[3], b[3];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int j = LANE + 64 * (3 * c3 + k3);
+            b[k3] = L.band_of_line[j];
+            const float igain = L.gig[c][b[k3]];
+            if (opt) {
+                float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
+                int iq = (int) t;
+                if (iq > 31) iq = 31;
+                q[k3] = (int) (t - L.quant_off[iq < 0 ? 0 : iq]);
+            } else {
+                q[k3] = (int) (igain * L.x34[c][j] + (0.5f - 0.0946f));
+            }
+        }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int j = LANE + 64 * (3 * c3 + k3);
+            if (j < nl) {
+                L.ix[c][j] = q[k3];
+                if (q[k3] > 0) atomicMax(&L.ixmax[c][b[k3]], q[k3]);
+            }
+        }
+    }
+}
+
 __device__ void do_quant(AllocLds &L, const AllocPrm *p, int opt)
 {
     const int ch = LANE >> 5, i = LANE & 31;
@@ -897,37 +963,10 @@ __device__ void do_quant(AllocLds &L, const AllocPrm *p, int opt)
     SYNC();
     // three lines per lane and chunk: band -> igain -> rounding offset are dependent LDS reads,
     // the three chains overlap; stores (and the band maximum) come after all loads of the chunk
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-        const int nl = p->nbmax[c];
-#pragma unroll 1
-        for (int c3 = 0; c3 < 3; c3++) {
-            if (192 * c3 >= nl) continue;
-            int q[3], b[3];
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int j = LANE + 64 * (3 * c3 + k3);
-                b[k3] = L.band_of_line[j];
-                const float igain = L.gig[c][b[k3]];
-                if (opt) {
-                    float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
-                    int iq = (int) t;
-                    if (iq > 31) iq = 31;
-                    q[k3] = (int) (t - L.quant_off[iq < 0 ? 0 : iq]);
-                } else {
-                    q[k3] = (int) (igain * L.x34[c][j] + (0.5f - 0.0946f));
-                }
-            }
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int j = LANE + 64 * (3 * c3 + k3);
-                if (j < nl) {
-                    L.ix[c][j] = q[k3];
-                    if (q[k3] > 0) atomicMax(&L.ixmax[c][b[k3]], q[k3]);
-                }
-            }
-        }
-    }
+    const bool two = p->nbmax[1] > 0;
+    if (two) HELPER_POST(HCMD_QUANT, opt);          // channel 1 on the helper wave
+    quant_lines(L, p, opt, 0);
+    if (two) HELPER_JOIN();
     SYNC();
 }
 
@@ -1213,8 +1252,11 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
 __device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
 {
     PROF_CNT(22);
+    // the channels are counted at the same time: channel 1 by the helper wave
+    const bool two = p->nchan == 2;
+    if (two) HELPER_POST(HCMD_COUNT_BITS, ncb[1]);
     int bits = count_bits_ch(L, p, 0, ncb[0]);
-    if (p->nchan == 2) bits += count_bits_ch(L, p, 1, ncb[1]);
+    if (two) { HELPER_JOIN(); bits += L.hs_bits[1]; }
     SYNC();
     return bits;
 }

@@ -68,6 +68,16 @@ struct hx_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double alloc_ms_sum = 0; int alloc_calls = 0;
+    // hx_batch_submit_*: the front-end kernels of call n+1 run (low-priority stream) while k_alloc of
+    // call n (high-priority stream) works through its slowest streams; a second set of the buffers
+    // that hand granules from the front end to k_alloc makes that safe.
+    float *d_xr2 = nullptr, *d_etab2 = nullptr, *d_thr2 = nullptr;
+    int *d_msbase2 = nullptr;
+    unsigned char *d_bt2 = nullptr, *d_btprev2 = nullptr;
+    hipStream_t s_front = nullptr, s_alloc = nullptr;
+    hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};
+    long long nsubmit = 0;
+    bool inflight = false;
 };
 
 extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
@@ -87,8 +97,13 @@ extern "C" void hx_batch_destroy(hx_batch *b)
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
-                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof};
+                    b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
+                    b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (b->s_front) hipStreamDestroy(b->s_front);
+    if (b->s_alloc) hipStreamDestroy(b->s_alloc);
+    hipEvent_t evs[] = {b->ev_in, b->ev_front[0], b->ev_front[1], b->ev_alloc[0], b->ev_alloc[1]};
+    for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (auto &pr : b->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete b;
 }
@@ -188,13 +203,55 @@ extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
     }
 }
 
-// one pass of the pipeline over the batch; the input is int16 (d_pcm) or fp32 at int16 scale (d_pcm32)
+// streams, events and the second buffer set of the submit path, created at the first submit
+static int pipe_init(hx_batch *b)
+{
+    if (b->s_front) return 0;
+    const long long S = b->S, NG = 2LL * b->maxF;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = least urgent, hi = most urgent
+    HIPCHK(hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&b->s_alloc, hipStreamNonBlocking, hi));
+    HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_alloc[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipMalloc((void **) &b->d_xr2, sizeof(float) * S * NG * 1152));
+    HIPCHK(hipMalloc((void **) &b->d_etab2, sizeof(float) * S * NG * 128));
+    HIPCHK(hipMalloc((void **) &b->d_thr2, sizeof(float) * S * NG * 128));
+    HIPCHK(hipMalloc((void **) &b->d_msbase2, sizeof(int) * S * NG));
+    HIPCHK(hipMalloc((void **) &b->d_bt2, S * NG));
+    HIPCHK(hipMalloc((void **) &b->d_btprev2, S));
+    return 0;
+}
+
+// one pass of the pipeline over the batch; the input is int16 (d_pcm) or fp32 at int16 scale (d_pcm32).
+// pipelined = 0: every kernel on the caller's stream.  pipelined = 1 (hx_batch_submit_*): front end
+// and k_alloc on the batch's own two streams, ordered by events (see hx_batch).
 static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, int nframes, unsigned char *d_out,
-                       long long out_stride, int *d_out_bytes, void *stream)
+                       long long out_stride, int *d_out_bytes, void *stream, int pipelined = 0)
 {
     if (!b || nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range"); return -1; }
-    hipStream_t q = (hipStream_t) stream;
+    hipStream_t q = (hipStream_t) stream, qa = q;
     HIPCHK(hipSetDevice(b->device));
+    int set = 0;
+    if (pipelined) {
+        if (pipe_init(b) != 0) return -1;
+        set = (int) (b->nsubmit & 1);
+        HIPCHK(hipEventRecord(b->ev_in, q));                        // the caller's PCM is ready from here on
+        HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_in, 0));
+        if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_alloc[set], 0));     // k_alloc of submit n-2 is done with this set
+        q = b->s_front; qa = b->s_alloc;
+    } else if (b->inflight) {                                       // a plain call behind submits: order it after them
+        const int last = (int) ((b->nsubmit - 1) & 1);
+        HIPCHK(hipStreamWaitEvent(q, b->ev_front[last], 0));
+        HIPCHK(hipStreamWaitEvent(q, b->ev_alloc[last], 0));
+        b->inflight = false;
+    }
+    float *const x_xr = set ? b->d_xr2 : b->d_xr, *const x_etab = set ? b->d_etab2 : b->d_etab, *const x_thr = set ? b->d_thr2 : b->d_thr;
+    int *const x_msbase = set ? b->d_msbase2 : b->d_msbase;
+    unsigned char *const x_bt = set ? b->d_bt2 : b->d_bt, *const x_btprev = set ? b->d_btprev2 : b->d_btprev;
     const int S = b->S, NG = 2 * nframes;
     const long long nsamp = 1152LL * nframes;
     // The subband carry sits in slots NG_prev..NG_prev+2 only if the previous call used another
@@ -209,24 +266,34 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     tot = S * NG;
     hipLaunchKernelGGL(k_attack_flg, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
                        b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
-    hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, b->d_bt, b->d_btprev, NG, S);
+    hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
     long long units = (long long) S * NG * 2;
-    hipLaunchKernelGGL(k_spec, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_gt, b->d_bt, b->d_xr,
-                       b->d_etab, b->d_thr, b->d_msbase, NG, SG);
+    hipLaunchKernelGGL(k_spec, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
+                       x_etab, x_thr, x_msbase, NG, SG);
+    // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
+    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
+    if (pipelined) {
+        HIPCHK(hipEventRecord(b->ev_front[set], q));
+        HIPCHK(hipStreamWaitEvent(qa, b->ev_front[set], 0));
+    }
     AllocArgs a;
-    a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = b->d_xr; a.etab = b->d_etab; a.thr = b->d_thr;
-    a.msbase = b->d_msbase; a.bt = b->d_bt; a.btprev = b->d_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
+    a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = x_xr; a.etab = x_etab; a.thr = x_thr;
+    a.msbase = x_msbase; a.bt = x_bt; a.btprev = x_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
     a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, q));
-    if (b->lsf) hipLaunchKernelGGL(k_alloc_lsf, dim3(S), dim3(64), 0, q, a);
-    else hipLaunchKernelGGL(k_alloc, dim3(S), dim3(64), 0, q, a);
-    HIPCHK(hipEventRecord(e1, q));
+    HIPCHK(hipEventRecord(e0, qa));
+    if (b->lsf) hipLaunchKernelGGL(k_alloc_lsf, dim3(S), dim3(128), 0, qa, a);
+    else hipLaunchKernelGGL(k_alloc, dim3(S), dim3(128), 0, qa, a);
+    HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
-    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
+    if (pipelined) {
+        HIPCHK(hipEventRecord(b->ev_alloc[set], qa));
+        b->nsubmit++;
+        b->inflight = true;
+    }
     HIPCHK(hipGetLastError());
     b->lastNG = NG;
     return 0;
@@ -242,6 +309,36 @@ extern "C" int hx_batch_encode_f32_device(hx_batch *b, const float *d_pcm, int n
                                           long long out_stride, int *d_out_bytes, void *stream)
 {
     return encode_core(b, nullptr, d_pcm, nframes, d_out, out_stride, d_out_bytes, stream);
+}
+
+// Pipelined form of the device calls.  A submit returns at once like the plain call, but its output
+// (d_out, d_out_bytes) is ordered on the caller's stream only by a later hx_batch_wait (or by the next
+// plain call / host-buffer call on the batch).  The PCM must be ready on `stream` at the submit, and
+// d_pcm must stay unchanged until the submit's front end has run (hx_batch_wait covers that too).
+// Consecutive submits overlap: the front end of call n+1 fills the SIMDs that k_alloc of call n
+// leaves idle while its slowest streams finish.
+extern "C" int hx_batch_submit_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
+                                          long long out_stride, int *d_out_bytes, void *stream)
+{
+    return encode_core(b, d_pcm, nullptr, nframes, d_out, out_stride, d_out_bytes, stream, 1);
+}
+
+extern "C" int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,
+                                          long long out_stride, int *d_out_bytes, void *stream)
+{
+    return encode_core(b, nullptr, d_pcm, nframes, d_out, out_stride, d_out_bytes, stream, 1);
+}
+
+// make `stream` wait for everything submitted so far
+extern "C" int hx_batch_wait(hx_batch *b, void *stream)
+{
+    if (!b) return -1;
+    if (!b->inflight) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    const int last = (int) ((b->nsubmit - 1) & 1);
+    HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_front[last], 0));
+    HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_alloc[last], 0));
+    return 0;
 }
 
 extern "C" float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls)

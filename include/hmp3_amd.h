@@ -99,6 +99,17 @@ int hx_batch_encode_f32_device(hx_batch *b, const float *d_pcm, int nframes, uns
                                long long out_stride, int *d_out_bytes, void *stream);
 int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
                              long long out_stride, int *out_bytes);
+/* Pipelined form of the device calls (no reference equivalent: the reference encodes one frame per
+   call on the CPU).  A submit is asynchronous like the plain call, but its outputs are ordered on
+   `stream` only by a later hx_batch_wait (or by the next plain / host-buffer call on the batch); the
+   PCM must be ready on `stream` at the submit and stay unchanged until hx_batch_wait.  Consecutive
+   submits overlap: the front-end kernels of call n+1 run on the SIMDs that the allocator kernel of
+   call n leaves idle while its slowest streams finish. */
+int hx_batch_submit_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
+                               long long out_stride, int *d_out_bytes, void *stream);
+int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,
+                               long long out_stride, int *d_out_bytes, void *stream);
+int hx_batch_wait(hx_batch *b, void *stream);
 /* optional packet outputs of the batched calls: d_packet [nstreams][nframes][frame_stride] bytes,
    d_packet_bytes [nstreams][nframes][2] (the reference's nbytes_out[2] of every call: {size, 0},
    or the sizes of the two back-to-back packets of an MPEG-2 call); frame_stride >= the packet
