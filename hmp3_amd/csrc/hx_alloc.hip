@@ -100,17 +100,18 @@ struct alignas(16) AllocLds {
     unsigned short r_mf[32];            // pending frames: main-data bytes of the slot ...
     int r_off[32];                      // ... and offset of its header in the output buffer
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
-    int cmd, cmd_arg[3];                // work order for the helper wave (see HELPER_POST)
+    alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
 #ifdef HX_PROFILE
-    unsigned long long prof[64];
+    unsigned prof[36];                  // 36 slots x 4 bytes keeps the profile build at four workgroups per CU
 #endif
 };
 
 #ifdef HX_PROFILE
-#define PROF(id, stmt) do { SYNC(); long long t0_ = clock64(); stmt; SYNC(); if (LANE == 0) L.prof[id] += (unsigned long long) (clock64() - t0_); } while (0)
+// (only the master wave's time is booked: the helper wave runs some of the same functions)
+#define PROF(id, stmt) do { SYNC(); long long t0_ = clock64(); stmt; SYNC(); if (threadIdx.x == 0 && (id) < 36) L.prof[(id) % 36] += (unsigned) (clock64() - t0_); } while (0)
 #define PROF_T0() long long tp_ = clock64()
-#define PROF_CNT(id) do { if (LANE == 0) L.prof[id] += 1; } while (0)
-#define PROF_ACC(id) do { SYNC(); if (LANE == 0) L.prof[id] += (unsigned long long) (clock64() - tp_); tp_ = clock64(); } while (0)
+#define PROF_CNT(id) do { if (threadIdx.x == 0 && (id) < 36) L.prof[(id) % 36] += 1; } while (0)
+#define PROF_ACC(id) do { SYNC(); if (threadIdx.x == 0 && (id) < 36) L.prof[(id) % 36] += (unsigned) (clock64() - tp_); tp_ = clock64(); } while (0)
 #else
 #define PROF(id, stmt) do { stmt; } while (0)
 #define PROF_T0() do { } while (0)
@@ -134,12 +135,16 @@ struct alignas(16) AllocLds {
 // sleeps at the workgroup barrier until the master hands it one channel's share of a phase whose
 // channels are independent: HELPER_POST publishes the order in LDS and releases the helper,
 // HELPER_JOIN waits for it.  Everything else in this file is wave-local and never uses s_barrier.
+// Workgroup barrier with the LDS hand-over around it: own LDS writes done before, and no LDS read
+// of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
+// order memory accesses).
+#define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SWEEP_LOAD, HCMD_SWEEP };
-#define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmd = (c_); L.cmd_arg[0] = (a0_); } \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-#define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmd = (c_); L.cmd_arg[0] = (a0_); L.cmd_arg[1] = (a1_); } \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-#define HELPER_JOIN() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
+        WG_BARRIER(); } while (0)
+#define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \
+        WG_BARRIER(); } while (0)
+#define HELPER_JOIN() WG_BARRIER()
 
 // ---------------------------------------------------------------------------------------
 // bit staging: OR an n-bit field (n <= 32) at absolute bit position pos
