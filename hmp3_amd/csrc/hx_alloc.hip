@@ -37,6 +37,7 @@ struct AllocPrm {
     int nsfs, nbmax_s;
     struct { int npart; } psyS;
     int nchan, side_bytes;              // 1 / 17 for a mono stream (mode 3), 2 / 32 otherwise
+    int oflags;                         // optional outputs of the call: 1 = packets, 2 = debug taps, 4 = per-frame counters
 };
 
 struct alignas(16) AllocLds {
@@ -139,7 +140,7 @@ struct alignas(16) AllocLds {
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SWEEP_LOAD, HCMD_SWEEP };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SWEEP_LOAD, HCMD_SWEEP, HCMD_EMIT };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \
