@@ -8,7 +8,8 @@
 // 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz (what the GPU path encodes); everything else fails like an
 // unsupported file.
 // Batch mode encodes all files as one batch of streams (same channel count, same flags) and
-// reproduces per file exactly what the single-file loop writes.
+// reproduces per file exactly what the single-file loop writes.  Containers: RIFF, RIFX, RF64 / BW64, Wave64.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -20,11 +21,16 @@
 
 namespace {
 
-struct WavInfo { int channels = 0, rate = 0, bits = 0, type = 0; uint64_t data_bytes = 0; };
+struct WavInfo { int channels = 0, rate = 0, bits = 0, type = 0, bigendian = 0; uint64_t data_bytes = 0; };
 struct Options { HX_E_CONTROL ec; int xing_flag = 3 | 0x40, ignore_length = 0; };
 
-unsigned rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned) p[3] << 24); }
-unsigned rd16(const unsigned char *p) { return p[0] | (p[1] << 8); }
+// a header field of n bytes in the file's byte order
+uint64_t field(const unsigned char *p, int n, int be)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < n; i++) v |= (uint64_t) p[be ? n - 1 - i : i] << (8 * i);
+    return v;
+}
 
 bool read_exact(FILE *f, void *dst, size_t n) { return fread(dst, 1, n, f) == n; }
 bool skip_bytes(FILE *f, uint64_t n)
@@ -34,30 +40,81 @@ bool skip_bytes(FILE *f, uint64_t n)
     return true;
 }
 
-// RIFF walk up to the start of the "data" chunk (works on pipes: no seeking)
+// Walk to the start of the audio data (works on pipes: no seeking).  Containers and rules as the
+// reference's pcmhead_file (pcmhpm.c:203-429): RIFF, RIFX (big-endian fields and samples), RF64 / BW64
+// (64-bit data size in the ds64 chunk) and Sony Wave64 (GUID chunks, sizes include the 24-byte chunk
+// header, bodies padded to 8).  bits = 8 * block align / channels, or the valid-bits field of a
+// WAVE_FORMAT_EXTENSIBLE header; an odd data size is rounded up to even (the pad byte is read as audio).
 bool wav_header(FILE *f, WavInfo *w)
 {
-    unsigned char h[12];
-    if (!read_exact(f, h, 12) || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) return false;
+    static const unsigned char w64_riff[16] = {0x72, 0x69, 0x66, 0x66, 0x2E, 0x91, 0xCF, 0x11, 0xA5, 0xD6, 0x28, 0xDB, 0x04, 0xC1, 0x00, 0x00};
+    static const unsigned char w64_tail[12] = {0xF3, 0xAC, 0xD3, 0x11, 0x8C, 0xD1, 0x00, 0xC0, 0x4F, 0x8E, 0xDB, 0x8A};   // wave / fmt / data GUIDs after their four letters
+    static const unsigned char ext_tail[14] = {0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xaa, 0x00, 0x38, 0x9b, 0x71};
+    unsigned char h[24];
+    bool w64 = false, rf64 = false;
+    uint64_t ds64_data = 0;
+    if (!read_exact(f, h, 8)) return false;
+    if (!memcmp(h, "RIFF", 4)) { }
+    else if (!memcmp(h, "RF64", 4) || !memcmp(h, "BW64", 4)) rf64 = true;
+    else if (!memcmp(h, "RIFX", 4)) w->bigendian = 1;
+    else {
+        if (!read_exact(f, h + 8, 16) || memcmp(h, w64_riff, 16)) return false;
+        w64 = true;
+    }
+    const int be = w->bigendian;
+    if (w64) { if (!read_exact(f, h, 16) || memcmp(h, "wave", 4) || memcmp(h + 4, w64_tail, 12)) return false; }
+    else if (!read_exact(f, h, 4) || memcmp(h, "WAVE", 4)) return false;
+    if (rf64) {
+        unsigned char d[36];
+        if (!read_exact(f, d, 36) || memcmp(d, "ds64", 4)) return false;
+        uint64_t size = field(d + 4, 4, be) + 8;
+        if (size < 36) return false;
+        if (size & 1) size++;
+        ds64_data = field(d + 16, 8, be);
+        if (!skip_bytes(f, size - 36)) return false;
+    }
     bool have_fmt = false;
     for (;;) {
-        unsigned char c[8];
-        if (!read_exact(f, c, 8)) return false;
-        const unsigned n = rd32(c + 4);
-        if (!memcmp(c, "fmt ", 4)) {
-            std::vector<unsigned char> b(n + (n & 1));
-            if (n < 16 || !read_exact(f, b.data(), b.size())) return false;
-            w->type = (int) rd16(&b[0]);
-            w->channels = (int) rd16(&b[2]);
-            w->rate = (int) rd32(&b[4]);
-            w->bits = (int) rd16(&b[14]);
-            if (w->type == 0xFFFE && n >= 26) w->type = (int) rd16(&b[24]);    // WAVE_FORMAT_EXTENSIBLE: sub-format
+        uint64_t n;     // body bytes to consume, padding included
+        bool is_fmt, is_data;
+        if (w64) {
+            if (!read_exact(f, h, 24)) return false;
+            n = field(h + 16, 8, 0);
+            if (n < 24) return false;
+            n -= 24;
+            if (n % 8) n += 8 - n % 8;
+            const bool ours = !memcmp(h + 4, w64_tail, 12);
+            is_fmt = ours && !memcmp(h, "fmt ", 4);
+            is_data = ours && !memcmp(h, "data", 4);
+        } else {
+            if (!read_exact(f, h, 8)) return false;
+            n = field(h + 4, 4, be);
+            is_fmt = !memcmp(h, "fmt ", 4);
+            is_data = !memcmp(h, "data", 4);
+            if ((n & 1) && n != 0xFFFFFFFFu) n++;
+            if (is_data && rf64 && n == 0xFFFFFFFFu) { n = ds64_data; if (n & 1) n++; }
+        }
+        if (is_fmt && !have_fmt) {
+            if (n < 16 || n >= (1u << 31)) return false;
+            std::vector<unsigned char> b((size_t) n);
+            if (!read_exact(f, b.data(), b.size())) return false;
+            w->type = (int) field(&b[0], 2, be);
+            w->channels = (int) field(&b[2], 2, be);
+            w->rate = (int) field(&b[4], 4, be);
+            w->bits = (int) field(&b[14], 2, be);
+            if (w->channels > 0) w->bits = 8 * ((int) field(&b[12], 2, be) / w->channels);
+            if (w->type == 65534 && n >= 18 + 22 && field(&b[16], 2, be) >= 22) {      // WAVE_FORMAT_EXTENSIBLE
+                if (!memcmp(&b[24 + 2], ext_tail, 14)) w->type = (int) field(&b[24], 2, be);
+                w->bits = (int) field(&b[18], 2, be);
+            }
             have_fmt = true;
-        } else if (!memcmp(c, "data", 4)) {
-            if (!have_fmt) return false;
+        } else if (is_data && have_fmt) {
             w->data_bytes = n;
             return true;
-        } else if (!skip_bytes(f, (uint64_t) n + (n & 1))) return false;
+        } else {
+            if (n >= (1u << 31)) return false;
+            if (!skip_bytes(f, n)) return false;
+        }
     }
 }
 
@@ -90,7 +147,8 @@ bool load_input(const char *path, const Options &opt, Input *in)
     const int ignore_length = opt.ignore_length || f == stdin;
     if (!wav_header(f, &in->wi)) { fprintf(stderr, "\n UNRECOGNIZED PCM FILE TYPE\n"); return false; }
     const WavInfo &wi = in->wi;
-    const uint64_t indatasize = ignore_length ? UINT64_MAX : wi.data_bytes;
+    // a data size of 0xFFFFFFFF means "until the end of the file" (tomp3.cpp:751-768)
+    const uint64_t indatasize = (ignore_length || wi.data_bytes == 0xFFFFFFFFu) ? UINT64_MAX : wi.data_bytes;
     if (indatasize == 0) { fprintf(stderr, "\n INPUT FILE CONTAINS NO AUDIO\n"); return false; }
     fprintf(stderr, "\n pcm file:  channels = %d  bits = %d,  rate = %d  type = %d", wi.channels, wi.bits, wi.rate, wi.type);
     in->is_float = wi.type == 3;
@@ -116,6 +174,10 @@ bool load_input(const char *path, const Options &opt, Input *in)
         const size_t got = fread(chunk.data(), 1, want, f);
         in->data.insert(in->data.end(), chunk.begin(), chunk.begin() + got);
         if (got < want) break;
+    }
+    if (wi.bigendian && wi.bits > 8) {      // cvt_to_pcm (pcmhpm.c:454-484): samples to host byte order
+        const size_t bs = (size_t) wi.bits / 8, ns = in->data.size() / bs;
+        for (size_t i = 0; i < ns; i++) std::reverse(in->data.begin() + i * bs, in->data.begin() + (i + 1) * bs);
     }
     in->audio_bytes = in->data.size();
     in->data.resize(in->data.size() + 4 * (size_t) in->frame_in, 0);

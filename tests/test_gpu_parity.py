@@ -80,7 +80,9 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
                                   "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k",
                                   "cli_downmix_vbr50_s16_44k", "cli_downmix_cbr64_s24_48k",
                                   "cli_lsf_cbr64_s16_22k", "cli_lsf_vbr50_f32_24k", "cli_lsf_mono_cbr24_s16_16k",
-                                  "cli_lsf_downmix_vbr80_s24_22k"])
+                                  "cli_lsf_downmix_vbr80_s24_22k",
+                                  "cli_rifx_cbr64_s16_44k", "cli_rf64_vbr50_s16_48k", "cli_w64_cbr64_s24_44k",
+                                  "cli_ext_vbr60_s24_48k", "cli_odd_cbr64_u8_mono_44k"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
     reference CLI (tests/golden/cli_*.mp3, tools/make_golden_cli.py)"""
@@ -91,7 +93,7 @@ def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     import make_golden_cli as M
     seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
     wav, mp3 = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3")
-    M.write_wav(wav, M.case_pcm(name), sr, as_float)
+    M.write_wav(wav, M.case_pcm(name), sr, as_float, M.CONTAINER.get(name))
     exe = os.path.join(root, "hmp3_amd", "hmp3amd")
     assert os.path.exists(exe), "hmp3_amd/build.sh builds the CLI"
     r = subprocess.run([exe, wav, mp3] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

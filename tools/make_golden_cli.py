@@ -35,12 +35,72 @@ CASES = {
     "cli_lsf_vbr50_f32_24k": (912, 60013, 24000, True, True, ["-V50"]),
     "cli_lsf_mono_cbr24_s16_16k": (913, 50021, 16000, False, True, ["-B24"]),
     "cli_lsf_downmix_vbr80_s24_22k": (914, 40009, 22050, 24, False, ["-M3", "-V80"]),
+    # other containers / header variants the reference parses (pcmhpm.c:203-429)
+    "cli_rifx_cbr64_s16_44k": (915, 30011, 44100, False, False, ["-B64"]),            # big-endian fields and samples
+    "cli_rf64_vbr50_s16_48k": (916, 30013, 48000, False, True, []),                   # ds64 chunk, data size 0xFFFFFFFF
+    "cli_w64_cbr64_s24_44k": (917, 30001, 44100, 24, False, ["-B64"]),                # Sony Wave64 GUID chunks
+    "cli_ext_vbr60_s24_48k": (918, 30007, 48000, 24, False, ["-V60"]),                # WAVE_FORMAT_EXTENSIBLE + a LIST chunk
+    "cli_odd_cbr64_u8_mono_44k": (919, 30001, 44100, 8, False, ["-B64"]),             # odd data size: the pad byte counts
 }
-MONO = {"cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k", "cli_lsf_mono_cbr24_s16_16k"}
+CONTAINER = {"cli_rifx_cbr64_s16_44k": "rifx", "cli_rf64_vbr50_s16_48k": "rf64", "cli_w64_cbr64_s24_44k": "w64",
+             "cli_ext_vbr60_s24_48k": "ext"}
+MONO = {"cli_odd_cbr64_u8_mono_44k", "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k", "cli_lsf_mono_cbr24_s16_16k"}
 
 
-def write_wav(path, pcm_i16, sr, as_float):
+def write_container(path, kind, fmt_tag, nch, sr, bits, data):
+    """the same sample bytes in one of the other containers the reference reads"""
+    be = kind == "rifx"
+    e = ">" if be else "<"
+    bps = bits // 8
+    if be and bps > 1:
+        data = b"".join(data[i:i + bps][::-1] for i in range(0, len(data), bps))
+    fmt = struct.pack(e + "HHIIHH", fmt_tag, nch, sr, sr * nch * bps, nch * bps, bits)
+    if kind == "ext":
+        guid = struct.pack("<H", fmt_tag) + bytes([0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xaa, 0x00, 0x38, 0x9b, 0x71])
+        fmt = struct.pack("<HHIIHH", 0xFFFE, nch, sr, sr * nch * bps, nch * bps, bits) + struct.pack("<HHI", 22, bits, 3) + guid
+    pad = b"\0" if len(data) & 1 else b""
+    with open(path, "wb") as f:
+        if kind == "w64":
+            tail = bytes([0xF3, 0xAC, 0xD3, 0x11, 0x8C, 0xD1, 0x00, 0xC0, 0x4F, 0x8E, 0xDB, 0x8A])
+            riff = bytes([0x72, 0x69, 0x66, 0x66, 0x2E, 0x91, 0xCF, 0x11, 0xA5, 0xD6, 0x28, 0xDB, 0x04, 0xC1, 0x00, 0x00])
+            p8 = lambda b: b + b"\0" * (-len(b) % 8)
+            body = b"wave" + tail + b"fmt " + tail + struct.pack("<Q", 24 + len(fmt)) + p8(fmt) + b"data" + tail + struct.pack("<Q", 24 + len(data)) + p8(data)
+            f.write(riff + struct.pack("<Q", 24 + len(body)) + body)
+        elif kind == "rf64":
+            ds64 = b"ds64" + struct.pack("<IQQQI", 28, 0, len(data), len(data) // (nch * bps), 0)
+            f.write(b"RF64" + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + ds64 + b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+            f.write(b"data" + struct.pack("<I", 0xFFFFFFFF) + data + pad)
+        else:
+            extra = b"LIST" + struct.pack(e + "I", 5) + b"INFOx\0" if kind == "ext" else b""     # an odd-sized chunk to skip
+            total = 4 + 8 + len(fmt) + len(extra) + 8 + len(data) + len(pad)
+            f.write((b"RIFX" if be else b"RIFF") + struct.pack(e + "I", total) + b"WAVE")
+            f.write(b"fmt " + struct.pack(e + "I", len(fmt)) + fmt + extra)
+            f.write(b"data" + struct.pack(e + "I", len(data)) + data + pad)
+
+
+def write_wav(path, pcm_i16, sr, as_float, container=None):
     n = pcm_i16.shape[0]
+    if container:       # integer PCM only
+        bits = as_float if as_float in (8, 24, 32) else 16
+        rng = np.random.default_rng(n)
+        if bits == 16:
+            data = pcm_i16.astype("<i2").tobytes()
+        elif bits == 24:
+            v = (pcm_i16.astype(np.int32) << 8) + rng.integers(0, 256, pcm_i16.shape)
+            b = v.astype("<i4").tobytes()
+            data = b"".join(b[i:i + 3] for i in range(0, len(b), 4))
+        else:
+            raise ValueError(bits)
+        write_container(path, container, 1, pcm_i16.shape[1] if pcm_i16.ndim == 2 else 1, sr, bits, data)
+        return n
+    if pcm_i16.ndim == 1 and as_float == 8:     # mono 8-bit unsigned (an odd sample count leaves an odd data size)
+        data = ((pcm_i16.astype(np.int32) >> 8) + 128).astype(np.uint8).tobytes()
+        fmt = struct.pack("<HHIIHH", 1, 1, sr, sr, 1, 8)
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data) + (len(data) & 1)) + b"WAVE")
+            f.write(b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+            f.write(b"data" + struct.pack("<I", len(data)) + data + (b"\x80" if len(data) & 1 else b""))
+        return n
     if pcm_i16.ndim == 1:       # mono: 16-bit or float only
         data = (pcm_i16.astype(np.float32) / 32768.0).astype("<f4").tobytes() if as_float is True else pcm_i16.astype("<i2").tobytes()
         bps = 4 if as_float is True else 2
@@ -96,7 +156,7 @@ if __name__ == "__main__":
     for name, (seed, nsamp, sr, as_float, bursts, flags) in CASES.items():
         with tempfile.TemporaryDirectory() as d:
             wav, mp3 = os.path.join(d, "in.wav"), os.path.join(d, "out.mp3")
-            write_wav(wav, case_pcm(name), sr, as_float)
+            write_wav(wav, case_pcm(name), sr, as_float, CONTAINER.get(name))
             subprocess.run([ref, wav, mp3] + flags, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             data = open(mp3, "rb").read()
         open(os.path.join(gold, name + ".mp3"), "wb").write(data)
