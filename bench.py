@@ -133,12 +133,13 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
     ap.add_argument("--frames", type=int, default=256, help="frames per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="hx_batch_submit_s16_device / hx_batch_wait instead of plain calls")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain hx_batch_encode_s16_device calls instead of submit / wait")
+    ap.add_argument("--gate", type=int, default=-1, help="hx_batch_set_gate percent (library default 90)")
     args = ap.parse_args()
 
     import torch
@@ -160,6 +161,8 @@ def main():
     sr = 44100
     ec = api.default_control(bitrate=64, short_block_threshold=99999)
     batch = api.Batch(ec, nstreams=S, max_frames=F, device=local)
+    if args.gate >= 0:
+        batch.set_gate(args.gate)
     pcm = synth_batch_gpu(torch, S, F, sr, dev, first_stream=rank * S)
     stride = batch.out_stride(F)
     out = torch.empty((S, stride), dtype=torch.uint8, device=dev)
@@ -167,9 +170,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        # --pipeline: hx_batch_submit_s16_device lets the front end of step n+1 overlap step n's allocator kernel.
-        # Measured slower (the front-end kernels slow the allocator's waves more than the overlap saves), so off.
-        if args.pipeline:
+        # hx_batch_submit_s16_device: the front-end kernels of step n+1 run in the tail of step n's allocator kernel
+        # (its slowest streams), on the SIMDs the finished streams have left; all of every step's work completes
+        # inside the timed region (hx_batch_wait + synchronize in barrier()).  --no-pipeline: plain calls.
+        if not args.no_pipeline:
             batch.submit_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
         else:
             batch.encode_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)

@@ -42,7 +42,7 @@ EXPORTS = [
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
-    "hx_batch_submit_s16_device", "hx_batch_submit_f32_device", "hx_batch_wait",
+    "hx_batch_submit_s16_device", "hx_batch_submit_f32_device", "hx_batch_wait", "hx_batch_set_gate",
     "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host",
     "hx_xing_create", "hx_xing_destroy", "hx_xing_header", "hx_xing_toc", "hx_xing_update_info", "hx_xing_update_crc", "hx_xing_bitrate_index", "hx_batch_status",
     "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
@@ -106,6 +106,8 @@ def lib():
         L.hx_batch_submit_s16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_submit_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.hx_batch_set_gate.argtypes = [C.c_void_p, C.c_int]
+        L.hx_batch_set_gate.restype = None
         L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
         L.hx_batch_status.argtypes = [C.c_void_p]
@@ -185,6 +187,9 @@ class Batch:
         r = lib().hx_batch_submit_s16_device(self.h, d_pcm_ptr, nframes, d_out_ptr, out_stride, d_out_bytes_ptr, stream)
         if r != 0:
             raise RuntimeError("hx_batch_submit_s16_device failed: " + last_error())
+
+    def set_gate(self, percent):
+        lib().hx_batch_set_gate(self.h, percent)
 
     def wait(self, stream=None):
         if lib().hx_batch_wait(self.h, stream) != 0:

@@ -27,8 +27,9 @@ struct AllocArgs {
     HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
     const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
     unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status; unsigned long long *prof;
-    unsigned char *packet; long long packet_stride; int *packet_bytes; int *frame_stats;
+    unsigned char *packet; long long packet_stride; int *packet_bytes; int *frame_stats; int *done_counter;
 };
+__global__ void k_gate(const int *done_counter, int target);
 __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
 
@@ -78,6 +79,9 @@ struct hx_batch {
     hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};
     long long nsubmit = 0;
     bool inflight = false;
+    int *d_done = nullptr;              // streams retired by all k_alloc launches of this batch
+    long long alloc_launches = 0;
+    int gate_percent = 90;              // a submit's front end starts once this share of the previous call's streams is done
 };
 
 extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
@@ -98,7 +102,7 @@ extern "C" void hx_batch_destroy(hx_batch *b)
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
                     b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
-                    b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2};
+                    b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done};
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->s_front) hipStreamDestroy(b->s_front);
     if (b->s_alloc) hipStreamDestroy(b->s_alloc);
@@ -159,6 +163,8 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_btprev, S);
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
+    ALLOC(b->d_done, sizeof(int));
+    HIPCHKN(hipMemset(b->d_done, 0, sizeof(int)));
     if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 1152 * b->nchan);
     HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(b->d_gt, &gt, sizeof(gt), hipMemcpyHostToDevice));
@@ -243,6 +249,10 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_in, 0));
         if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_alloc[set], 0));     // k_alloc of submit n-2 is done with this set
         q = b->s_front; qa = b->s_alloc;
+        if (b->alloc_launches > 0 && b->gate_percent > 0) {        // start in the previous allocator kernel's tail, not at its start
+            const long long target = (b->alloc_launches - 1) * b->S + (long long) b->S * b->gate_percent / 100;
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, b->d_done, (int) target);
+        }
     } else if (b->inflight) {                                       // a plain call behind submits: order it after them
         const int last = (int) ((b->nsubmit - 1) & 1);
         HIPCHK(hipStreamWaitEvent(q, b->ev_front[last], 0));
@@ -281,6 +291,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.msbase = x_msbase; a.bt = x_bt; a.btprev = x_btprev; a.out = d_out; a.out_bytes = d_out_bytes;
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
     a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
+    a.done_counter = b->d_done;
+    b->alloc_launches++;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -328,6 +340,9 @@ extern "C" int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int n
 {
     return encode_core(b, nullptr, d_pcm, nframes, d_out, out_stride, d_out_bytes, stream, 1);
 }
+
+// share (percent) of the previous call's streams that must be done before a submit's front end starts; 0 = no gate
+extern "C" void hx_batch_set_gate(hx_batch *b, int percent) { if (b) b->gate_percent = percent < 0 ? 0 : (percent > 100 ? 100 : percent); }
 
 // make `stream` wait for everything submitted so far
 extern "C" int hx_batch_wait(hx_batch *b, void *stream)

@@ -684,3 +684,18 @@ __global__ void k_dcfilter(const int16_t *__restrict__ pcm, const float *__restr
     }
     ss->dc[ch] = d;
 }
+
+// Gate of a pipelined submit (hx_batch_submit_*): holds the stream it is launched on until the
+// allocator kernel of the previous call has retired `target` streams in total, so that the front-end
+// kernels behind it start in that kernel's tail instead of competing with its start.  Gives up after
+// ~50 ms (s_memtime ticks at 100 MHz): late is harmless, a hang is not.
+__global__ void k_gate(const int *done_counter, int target)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = clock64();
+    while (__hip_atomic_load(done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(127);
+        if (clock64() - t0 > 5000000LL) break;
+    }
+}
+

@@ -110,6 +110,9 @@ int hx_batch_submit_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, u
 int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,
                                long long out_stride, int *d_out_bytes, void *stream);
 int hx_batch_wait(hx_batch *b, void *stream);
+/* a submit's front end is held back until this share (percent, default 90) of the previous call's streams has
+   left the allocator kernel, so that it runs in that kernel's tail; 0 starts it at once */
+void hx_batch_set_gate(hx_batch *b, int percent);
 /* optional packet outputs of the batched calls: d_packet [nstreams][nframes][frame_stride] bytes,
    d_packet_bytes [nstreams][nframes][2] (the reference's nbytes_out[2] of every call: {size, 0},
    or the sizes of the two back-to-back packets of an MPEG-2 call); frame_stride >= the packet

@@ -234,35 +234,41 @@ def test_mpeg2_packet_variant_matches_oracle(kw):
 
 
 def test_pipelined_submit_equals_plain_calls_and_oracle():
-    """hx_batch_submit_s16_device / hx_batch_wait: consecutive calls overlap on two internal streams; the bytes
-    must not change, also when plain and host-buffer calls are mixed in"""
+    """hx_batch_submit_s16_device / hx_batch_wait: consecutive calls overlap on two internal streams (the front end
+    of call n+1 gated into the tail of call n's allocator kernel); the bytes must not change, also when plain calls
+    are mixed in.  Every stream against a batch driven by plain calls, a sample of them against the oracle."""
     import torch
     kw = dict(bitrate=64)
-    S, F = 64, 8
-    calls = 7
+    S, F = 512, 12
+    calls = 6
     pcm = np.stack([synth.stream_pcm(900 + i, F * calls, rho=RHOS[i % 4], bursts=True) for i in range(S)])
     dev = torch.device("cuda:0")
-    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
-    stride = b.out_stride(F)
-    d_pcm = [torch.from_numpy(np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])).to(dev) for c in range(calls)]
-    d_out = [torch.zeros((S, stride), dtype=torch.uint8, device=dev) for _ in range(calls)]
-    d_nb = [torch.zeros((S,), dtype=torch.int32, device=dev) for _ in range(calls)]
     st = torch.cuda.current_stream().cuda_stream
-    torch.cuda.synchronize()
-    for c in range(calls):
-        if c == 4:      # a plain call in the middle of the submits
-            b.encode_device(d_pcm[c].data_ptr(), F, d_out[c].data_ptr(), stride, d_nb[c].data_ptr(), st)
-        else:
-            b.submit_device(d_pcm[c].data_ptr(), F, d_out[c].data_ptr(), stride, d_nb[c].data_ptr(), st)
-    b.wait(st)
-    torch.cuda.synchronize()
-    assert b.status() == 0
-    outs = [o.cpu().numpy() for o in d_out]
-    nbs = [n.cpu().numpy() for n in d_nb]
-    for s in range(S):
-        got = b"".join(outs[c][s, :nbs[c][s]].tobytes() for c in range(calls))
-        assert got == oracle_bytes(kw, pcm[s], F * calls), "stream %d" % s
-    b.close()
+    d_pcm = [torch.from_numpy(np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])).to(dev) for c in range(calls)]
+    got = {}
+    for mode in ("plain", "submit_gate90", "submit_gate0"):
+        b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+        if mode == "submit_gate0":
+            b.set_gate(0)
+        stride = b.out_stride(F)
+        d_out = [torch.zeros((S, stride), dtype=torch.uint8, device=dev) for _ in range(calls)]
+        d_nb = [torch.zeros((S,), dtype=torch.int32, device=dev) for _ in range(calls)]
+        torch.cuda.synchronize()
+        for c in range(calls):
+            if mode == "plain" or c == 3:      # a plain call in the middle of the submits
+                b.encode_device(d_pcm[c].data_ptr(), F, d_out[c].data_ptr(), stride, d_nb[c].data_ptr(), st)
+            else:
+                b.submit_device(d_pcm[c].data_ptr(), F, d_out[c].data_ptr(), stride, d_nb[c].data_ptr(), st)
+        b.wait(st)
+        torch.cuda.synchronize()
+        assert b.status() == 0
+        outs = [o.cpu().numpy() for o in d_out]
+        nbs = [n.cpu().numpy() for n in d_nb]
+        got[mode] = [b"".join(outs[c][s, :nbs[c][s]].tobytes() for c in range(calls)) for s in range(S)]
+        b.close()
+    assert got["submit_gate90"] == got["plain"] and got["submit_gate0"] == got["plain"]
+    for s in range(0, S, 64):
+        assert got["plain"][s] == oracle_bytes(kw, pcm[s], F * calls), "stream %d" % s
 
 
 def test_float_input_and_dc_filter_mixed_batch():
