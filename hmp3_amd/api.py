@@ -42,6 +42,7 @@ EXPORTS = [
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
+    "hx_src_create", "hx_src_destroy", "hx_src_init", "hx_src_convert",
     "hx_batch_submit_s16_device", "hx_batch_submit_f32_device", "hx_batch_wait", "hx_batch_set_gate",
     "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host",
     "hx_xing_create", "hx_xing_destroy", "hx_xing_header", "hx_xing_toc", "hx_xing_update_info", "hx_xing_update_crc", "hx_xing_bitrate_index", "hx_batch_status",

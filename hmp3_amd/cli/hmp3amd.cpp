@@ -5,8 +5,8 @@
 // test/tomp3.cpp:336-602 main, :645-1088 ff_encode): Xing/Info tag frame first, audio frames, four
 // frames of silence behind the input, drain until every submitted frame is out, then the tag is
 // completed in place.  Accepted: RIFF/WAVE, mono or stereo, 8/16/24/32-bit PCM or 32-bit float,
-// 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz (what the GPU path encodes); everything else fails like an
-// unsupported file.
+// 8 - 48 kHz (rates other than 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz, or -A, go through the sample-rate
+// converter first, as in the reference); everything else fails like an unsupported file.
 // Batch mode encodes all files as one batch of streams (same channel count, same flags) and
 // reproduces per file exactly what the single-file loop writes.  Containers: RIFF, RIFX, RF64 / BW64, Wave64.
 #include <algorithm>
@@ -22,7 +22,7 @@
 namespace {
 
 struct WavInfo { int channels = 0, rate = 0, bits = 0, type = 0, bigendian = 0; uint64_t data_bytes = 0; };
-struct Options { HX_E_CONTROL ec; int xing_flag = 3 | 0x40, ignore_length = 0; };
+struct Options { HX_E_CONTROL ec; int xing_flag = 3 | 0x40, ignore_length = 0, mpeg_select = 0; };
 
 // a header field of n bytes in the file's byte order
 uint64_t field(const unsigned char *p, int n, int be)
@@ -126,18 +126,25 @@ void usage()
             "\n   -Bn  kbps per channel (CBR)      -Vn  VBR quality 0..150 (default 50)"
             "\n   -Mn  0 stereo, 1 joint stereo, 3 mono      -Fn  low-pass Hz      -HFn high-frequency mode"
             "\n   -SBTn short-block threshold      -S1  DC blocker       -Xn  0 no tag, 1 Xing, 2/3 + TOC, default + info"
-            "\n   -Cn -On copyright / original bits   -Ln VBR bitrate cap   -Tn -TXn tuning   -IL ignore the WAV length field\n");
+            "\n   -Cn -On copyright / original bits   -Ln VBR bitrate cap   -Tn -TXn tuning   -IL ignore the WAV length field"
+            "\n   -An  encode rate: 0 track the input (default), 1 an MPEG-1 rate, 2 an MPEG-2 rate, else that rate in Hz\n");
 }
 
 // one input file, read and checked
 struct Input {
     WavInfo wi;
-    std::vector<unsigned char> data;    // the audio bytes followed by four frames of zero bytes
+    std::vector<unsigned char> data;    // the audio bytes; pad() appends the silence the encode loop runs into
     uint64_t audio_bytes = 0;
     int frame_in = 0, mono_convert = 0, is_float = 0;
     HX_E_CONTROL ec;                    // as given to the encoder
     HX_E_CONTROL ec_used;               // as reported back (settings in use)
     HX_MPEG_HEAD head;
+    size_t size = 0;                    // bytes the encode loop may consume: audio + 4 x init_bytes of zero bytes
+    // The reference refills a large buffer and, when it meets the end of the data, appends 4 x bytes_in_init
+    // zero bytes (tomp3.cpp:925-934); a call is made while at least bytes_in_init bytes are left (:904-941).
+    // A linear buffer of (data ++ zeros) gives the same sequence of calls.  The converter may stage more
+    // than it consumes, so some slack follows.
+    void pad(int init_bytes) { size = audio_bytes + 4 * (size_t) init_bytes; data.resize(size + (1 << 17), 0); }
 };
 
 bool load_input(const char *path, const Options &opt, Input *in)
@@ -154,8 +161,8 @@ bool load_input(const char *path, const Options &opt, Input *in)
     in->is_float = wi.type == 3;
     if ((wi.channels != 1 && wi.channels != 2) ||
         !((wi.type == 1 && (wi.bits == 8 || wi.bits == 16 || wi.bits == 24 || wi.bits == 32)) || (in->is_float && wi.bits == 32)) ||
-        (wi.rate != 32000 && wi.rate != 44100 && wi.rate != 48000 && wi.rate != 16000 && wi.rate != 22050 && wi.rate != 24000)) {
-        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n This build encodes mono or stereo 8/16/24/32-bit PCM or 32-bit float input at 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz.\n");
+        wi.rate < 8000 || wi.rate > 48000) {
+        fprintf(stderr, "\n UNSUPPORTED PCM FILE TYPE\n Mono or stereo, 8/16/24/32-bit PCM or 32-bit float, 8000 Hz - 48000 Hz.\n");
         return false;
     }
     in->ec = opt.ec;
@@ -165,8 +172,6 @@ bool load_input(const char *path, const Options &opt, Input *in)
     else if (in->ec.mode == 3) in->ec.mode = 1;
     in->ec.samprate = wi.rate;
     in->frame_in = 1152 * wi.channels * (wi.bits / 8);
-    // The reference refills a 256-frame buffer and appends the silence when it meets the end of the
-    // data; feeding whole frames of (data ++ 4 frames of zero bytes) is the same sequence of calls.
     std::vector<unsigned char> chunk(1 << 20);
     while (in->data.size() < indatasize) {
         size_t want = chunk.size();
@@ -180,7 +185,6 @@ bool load_input(const char *path, const Options &opt, Input *in)
         for (size_t i = 0; i < ns; i++) std::reverse(in->data.begin() + i * bs, in->data.begin() + (i + 1) * bs);
     }
     in->audio_bytes = in->data.size();
-    in->data.resize(in->data.size() + 4 * (size_t) in->frame_in, 0);
     if (f != stdin) fclose(f);
     return true;
 }
@@ -220,8 +224,10 @@ int encode_one_file(const char *fin, const char *fout, const Options &opt)
     Input in;
     if (!load_input(fin, opt, &in)) return 1;
     hx_enc *enc = hx_enc_create(0);
-    const int frame_in = enc ? hx_enc_MP3_audio_encode_init(enc, &in.ec, in.wi.bits, in.is_float, 0, in.mono_convert) : 0;
-    if (!frame_in) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
+    // bytes a call needs in the buffer (more than it consumes); with a sample-rate conversion a call consumes a varying amount
+    const int init_bytes = enc ? hx_enc_MP3_audio_encode_init(enc, &in.ec, in.wi.bits, in.is_float, opt.mpeg_select, in.mono_convert) : 0;
+    if (!init_bytes) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
+    in.pad(init_bytes);
     FILE *out = strcmp(fout, "-") ? fopen(fout, "w+b") : stdout;
     if (!out) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE\n"); return 1; }
     char info[128];
@@ -234,15 +240,17 @@ int encode_one_file(const char *fin, const char *fout, const Options &opt)
     uint64_t out_bytes = tg.head_bytes;
     if (tg.head_bytes && fwrite(tg.tag.data(), 1, tg.head_bytes, out) != (size_t) tg.head_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); return 1; }
 
-    std::vector<unsigned char> bs(128 * 1024), zero(frame_in, 0);
+    std::vector<unsigned char> bs(128 * 1024), zero((size_t) 4 * init_bytes + (1 << 17), 0);
     unsigned frames_expected = 0;
     auto emit = [&](const HX_IN_OUT &x) {
         if (x.out_bytes && fwrite(bs.data(), 1, x.out_bytes, out) != (size_t) x.out_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); exit(1); }
         tg.bytes(bs.data(), x.out_bytes);
         out_bytes += x.out_bytes;
     };
-    for (size_t off = 0; off + frame_in <= in.data.size(); off += frame_in) {      // tomp3.cpp:906-1003
-        emit(hx_enc_MP3_audio_encode(enc, in.data.data() + off, bs.data()));
+    for (size_t off = 0; off + init_bytes <= in.size; ) {                           // tomp3.cpp:904-1003
+        const HX_IN_OUT x = hx_enc_MP3_audio_encode(enc, in.data.data() + off, bs.data());
+        emit(x);
+        off += x.in_bytes;
         frames_expected++;
         const HX_INT_PAIR fb = hx_enc_get_frames_bytes(enc);
         tg.after_call((unsigned) fb.a, (unsigned) fb.b);
@@ -264,6 +272,15 @@ int encode_one_file(const char *fin, const char *fout, const Options &opt)
 
 // samples of one input frame as fp32 at int16 scale, the way Csrc::sr_convert / src_filter_to_mono_case0
 // produce them (srcc.cpp:804-836, srccf.cpp:458-468)
+// what hx_enc_MP3_audio_encode_init returns when source and encode rate are equal: 1153 sample frames
+int init_bytes_same_rate(const Input &in) { return 1153 * in.wi.channels * (in.wi.bits / 8); }
+// calls of the single-file loop: one per frame_in bytes while at least init_bytes are left
+size_t ncalls(const Input &in)
+{
+    const size_t init = (size_t) init_bytes_same_rate(in);
+    return in.size >= init ? (in.size - init) / (size_t) in.frame_in + 1 : 0;
+}
+
 void frame_to_float(const Input &in, const unsigned char *src, float *dst)
 {
     const int ns = 1152 * in.wi.channels;
@@ -297,7 +314,13 @@ int encode_batch(const std::vector<const char *> &files, const Options &opt)
         nch = c;
         if (!hx_control_info(&ec, &in[i].ec_used, &in[i].head)) { fprintf(stderr, "\n ENCODER INIT FAIL (%s)\n", files[2 * i]); return 1; }
         ctl[i] = ec;
-        const size_t calls = in[i].data.size() / in[i].frame_in;
+        const int r = in[i].wi.rate;
+        if (opt.mpeg_select || (r != 32000 && r != 44100 && r != 48000 && r != 16000 && r != 22050 && r != 24000)) {
+            fprintf(stderr, "\n -batch encodes files at their own MPEG sample rate; %s needs a rate conversion (use the single-file mode)\n", files[2 * i]);
+            return 1;
+        }
+        in[i].pad(init_bytes_same_rate(in[i]));
+        const size_t calls = ncalls(in[i]);
         if (calls > max_calls) max_calls = calls;
     }
     const int CH = 96;                                  // frames per batched call
@@ -313,7 +336,7 @@ int encode_batch(const std::vector<const char *> &files, const Options &opt)
     std::vector<std::vector<unsigned>> fr(S), by(S);    // per input frame: frames / bytes out so far
     for (size_t c0 = 0; c0 < total; c0 += CH) {
         for (int i = 0; i < S; i++) {
-            const size_t calls = in[i].data.size() / in[i].frame_in;
+            const size_t calls = ncalls(in[i]);
             for (int k = 0; k < CH; k++) {
                 // past the end the single-file loop feeds frames of zero BYTES: silence, except for
                 // 8-bit unsigned input where a zero byte is full-scale negative
@@ -336,7 +359,7 @@ int encode_batch(const std::vector<const char *> &files, const Options &opt)
     // per file: what the single-file loop would have written
     int rc = 0;
     for (int i = 0; i < S; i++) {
-        const size_t calls = in[i].data.size() / in[i].frame_in;
+        const size_t calls = ncalls(in[i]);
         Tagger tg;
         tg.begin(in[i], opt.xing_flag);
         for (size_t u = 0; u < calls; u++) tg.after_call(fr[i][u], by[i][u]);
@@ -391,7 +414,8 @@ int main(int argc, char **argv)
         case 'j': ec.chan_add_f1 = atoi(a + 2); break;
         case 'v': ec.vbr_flag = 1; ec.vbr_mnr = atoi(a + 2); break;
         case 'l': ec.vbr_br_limit = atoi(a + 2); break;
-        default: break;             // -D -EC -P -Z -A -W: display / reserved switches, no effect on the stream
+        case 'a': opt.mpeg_select = atoi(a + 2); if (opt.mpeg_select < 0) opt.mpeg_select = 0; break;
+        default: break;             // -D -EC -P -Z -W: display / reserved switches, no effect on the stream
         }
     }
     opt.ec.vbr_flag = opt.ec.bitrate < 0 ? 1 : 0;

@@ -10,6 +10,7 @@
 #include "../../include/hmp3_amd.h"
 #include "hx_types.h"
 #include "hx_host.h"
+#include "hx_src.h"
 
 // kernels (hx_front.hip / hx_alloc.hip)
 #define K1_GPB 14
@@ -526,6 +527,7 @@ struct hx_enc {
     std::vector<unsigned char> outbuf;
     unsigned frames = 0, bytes = 0;
     int ave = 0;
+    hx_src *src = nullptr;              // converter of the MP3_audio_encode entry points
     unsigned char *d_packet = nullptr;  // one reformatted frame (device), allocated on first *_Packet call
     int *d_packet_bytes = nullptr;
 };
@@ -542,6 +544,7 @@ extern "C" void hx_enc_destroy(hx_enc *e)
     if (!e) return;
     if (e->d_packet) hipFree(e->d_packet);
     if (e->d_packet_bytes) hipFree(e->d_packet_bytes);
+    hx_src_destroy(e->src);
     hx_batch_destroy(e->b);
     delete e;
 }
@@ -617,55 +620,78 @@ extern "C" HX_IN_OUT hx_enc_MP3_audio_encode_Packet(hx_enc *e, const unsigned ch
     return encode_packet(e, pcm, 1, bs_out, packet, nbytes_out);
 }
 
+static int nearest_rate(const int *table, int n, int x)
+{
+    int best = table[0], d0 = abs(table[0] - x);
+    for (int i = 0; i < n; i++) { const int d = abs(table[i] - x); if (d < d0) { d0 = d; best = table[i]; } }
+    return best;
+}
+
+// CMp3Enc::MP3_audio_encode_init (reference mp3enc.cpp:2655-2808): pick the encode rate for the source
+// rate and mpeg_select (0 track the input, 1 an MPEG-1 rate, 2 an MPEG-2 rate, else that rate), set up the
+// sample-format / rate converter (hx_src.cpp) and the encoder behind it.  Returns the bytes the caller
+// must hold before every hx_enc_MP3_audio_encode call (more than one call consumes: 1153 sample frames
+// when the rates are equal), 0 on failure.
 extern "C" int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, int source_bits, int source_is_float,
                                             int mpeg_select, int mono_convert)
 {
-    (void) mpeg_select;
-    // mp3enc.cpp:2693-2700: the source is mono iff ec->mode == 3; mono_convert encodes one channel
+    static const int rate_table[6] = {22050, 24000, 16000, 44100, 48000, 32000};
+    const int source = ec->samprate;
+    if (source < 4000 || source > 48000) { set_err("source sample rate out of range"); return 0; }
+    const int source_chan = (ec->mode == 3) ? 1 : 2;            // the source is mono iff ec->mode == 3
+    const int target_chan = mono_convert ? 1 : source_chan;
+    int target = 0;
+    if (mpeg_select < 0) mpeg_select = 0;
+    switch (mpeg_select) {
+    case 0:
+        if (source < 16000) { target = nearest_rate(rate_table, 3, 2 * source); if (target == 2 * source) break; }
+        target = nearest_rate(rate_table, 6, source);
+        break;
+    case 1:
+        if (source < 16000) { target = nearest_rate(rate_table + 3, 3, 4 * source); if (target == 4 * source) break; }
+        if (source < 32000) { target = nearest_rate(rate_table + 3, 3, 2 * source); if (target == 2 * source) break; }
+        target = nearest_rate(rate_table + 3, 3, source);
+        break;
+    case 2:
+        if (source < 16000) { target = nearest_rate(rate_table, 3, 2 * source); if (target == 2 * source) break; }
+        if (source > 24000) { target = nearest_rate(rate_table, 3, source / 2); if (2 * target == source) break; }
+        target = nearest_rate(rate_table, 3, source);
+        break;
+    default:
+        target = nearest_rate(rate_table, 6, mpeg_select);
+        if (target != mpeg_select) { set_err("mpeg_select is not an MPEG sample rate"); return 0; }
+        break;
+    }
+    if (!e->src) e->src = hx_src_create();
+    int cutoff = 0;
+    const int min_input_bytes = hx_src_init(e->src, source, source_chan, source_bits, source_is_float, target, target_chan, &cutoff);
+    if (min_input_bytes <= 0) { set_err("the sample-rate converter cannot handle this source format / rate pair"); return 0; }
+    int nsb_limit = (64 * cutoff + target / 2) / target;
+    if (nsb_limit > 30) nsb_limit = 30;
     HX_E_CONTROL ec2 = *ec;
-    const int src_chan = (ec->mode == 3) ? 1 : 2;
-    if (mono_convert) ec2.mode = 3;
-    if (!(source_bits == 8 || source_bits == 16 || source_bits == 24 || source_bits == 32)) { set_err("8, 16, 24 or 32-bit sources only"); return 0; }
-    if (source_is_float && source_bits != 32) { set_err("float sources are 32-bit"); return 0; }
-    const int sr = ec->samprate;    // an MPEG rate is encoded as it is (mpeg_select 0 = track the input, mp3enc.cpp:2655-2808)
-    if (sr != 32000 && sr != 44100 && sr != 48000 && sr != 16000 && sr != 22050 && sr != 24000) { set_err("sample-rate conversion is not on the GPU path"); return 0; }
-    int r = hx_enc_L3_audio_encode_init(e, &ec2);
-    if (!r) return 0;
+    ec2.samprate = target;
+    if (target_chan == 1) ec2.mode = 3;
+    if (source < target) {          // up-sampled input has nothing above the source's band
+        if (ec2.nsb_limit <= 0) ec2.nsb_limit = 30;
+        if (ec2.nsb_limit > nsb_limit) ec2.nsb_limit = nsb_limit;
+    }
+    ec2.layer = 3;
+    if (!hx_enc_L3_audio_encode_init(e, &ec2)) return 0;
     e->src_bits = source_bits;
     e->src_float = source_is_float;
-    e->src_chan = src_chan;
-    return 1152 * src_chan * (source_bits / 8);
+    e->src_chan = source_chan;
+    return min_input_bytes;
 }
 
+// CMp3Enc::MP3_audio_encode (mp3enc.cpp:2812-2828): convert, then encode; in_bytes is what the converter used.
+// pcm must hold the bytes hx_enc_MP3_audio_encode_init returned, and be readable for
+// 1152 * (source rate / encode rate + 1) sample frames (the converter stages that many).
 extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out)
 {
-    const int ns = 1152 * e->src_chan;      // samples per call
-    if (e->src_bits == 16 && e->src_chan == e->p.nchan) return encode_one(e, pcm, 0, bs_out, 2 * ns);
-    // every other sample format becomes fp32 at int16 scale exactly as Csrc::sr_convert does it
-    // (srcc.cpp:804-836), little-endian input
-    std::vector<float> t(ns);
-    if (e->src_bits == 32 && e->src_float) {
-        const float *f = (const float *) pcm;
-        for (int i = 0; i < ns; i++) t[i] = f[i] * 32768.0f;
-    } else if (e->src_bits == 32) {
-        const int *s = (const int *) pcm;
-        for (int i = 0; i < ns; i++) t[i] = (float) (s[i] / 65536.0f);
-    } else if (e->src_bits == 24) {
-        for (int i = 0; i < ns; i++) {
-            const unsigned char *b = pcm + 3 * i;
-            const int s = (int) (((unsigned) b[2] << 24) | ((unsigned) b[1] << 16) | ((unsigned) b[0] << 8)) >> 8;
-            t[i] = (float) ((float) s / 256.0f);
-        }
-    } else if (e->src_bits == 16) {
-        const int16_t *s = (const int16_t *) pcm;
-        for (int i = 0; i < ns; i++) t[i] = (float) s[i];
-    } else {
-        for (int i = 0; i < ns; i++) t[i] = (((float) pcm[i]) - 128.0f) * (256.0f);
-    }
-    if (e->src_chan == 2 && e->p.nchan == 1)        // stereo source, mono stream (srccf.cpp:458-468)
-        for (int i = 0; i < 1152; i++) t[i] = (float) ((t[2 * i] + t[2 * i + 1]) * 0.5);
-    HX_IN_OUT x = hx_enc_L3_audio_encode(e, t.data(), bs_out);
-    x.in_bytes = ns * (e->src_bits / 8);
+    float t[2304];
+    const int in_bytes = hx_src_convert(e->src, pcm, t, nullptr);
+    HX_IN_OUT x = hx_enc_L3_audio_encode(e, t, bs_out);
+    x.in_bytes = in_bytes;
     return x;
 }
 

@@ -54,12 +54,15 @@ void hx_enc_destroy(hx_enc *e);                             /* CMp3Enc::~CMp3Enc
 int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec);
 /* CMp3Enc::L3_audio_encode (mp3enc.cpp:2031): 1152 x 2 floats at int16 scale, oldest first */
 HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out);
-/* CMp3Enc::MP3_audio_encode_init (mp3enc.cpp:2655): 16-bit or float source at a native MPEG-1
-   rate, no rate conversion; returns min input bytes per call or 0 */
+/* CMp3Enc::MP3_audio_encode_init (mp3enc.cpp:2655): 8/16/24/32-bit PCM or 32-bit float source at
+   8 - 48 kHz, converted to the encode rate by the built-in converter; returns min input bytes per call or 0 */
 int hx_enc_MP3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec, int source_bits, int source_is_float,
                                  int mpeg_select, int mono_convert);
 /* CMp3Enc::MP3_audio_encode (mp3enc.cpp:2812) */
 HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out);
+/* (init returns the bytes a call needs buffered - 1153 sample frames when no rate conversion is involved -
+   and in_bytes of a call is what the converter consumed; mpeg_select: 0 track the input rate, 1 an MPEG-1
+   rate, 2 an MPEG-2 rate, else the encode rate in Hz) */
 int hx_enc_get_bitrate(hx_enc *e);                          /* mp3enc.cpp:3444 */
 float hx_enc_get_bitrate_float(hx_enc *e);                  /* mp3enc.cpp:3451 */
 float hx_enc_get_bitrate2_float(hx_enc *e);                 /* mp3enc.cpp:3468 */
@@ -75,6 +78,18 @@ void hx_enc_info_head(hx_enc *e, HX_MPEG_HEAD *head);       /* mp3enc.cpp:3498 *
 HX_IN_OUT hx_enc_L3_audio_encode_Packet(hx_enc *e, const float *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 HX_IN_OUT hx_enc_MP3_audio_encode_Packet(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 void hx_enc_info_string(hx_enc *e, char *s);                /* mp3enc.cpp:3505, <= 80 chars */
+
+/* ---- sample-format / sample-rate converter (host side) ----
+   What CMp3Enc::MP3_audio_encode runs in front of every frame: Csrc (pub/srcc.h:87-97).  hx_enc_MP3_audio_encode
+   uses it internally; it is exported for callers that feed the batched API from sources at other rates. */
+typedef struct hx_src hx_src;
+hx_src *hx_src_create(void);
+void hx_src_destroy(hx_src *s);
+/* Csrc::sr_convert_init (srcc.cpp:730): bytes to hold per convert call, 0 = unsupported pair */
+int hx_src_init(hx_src *s, int source, int channels, int bits, int is_float, int target, int target_channels,
+                int *encode_cutoff_freq);
+/* Csrc::sr_convert (srcc.cpp:795): 1152 samples per output channel, fp32 at int16 scale; returns input bytes used */
+int hx_src_convert(hx_src *s, const unsigned char *xin, float *yout, int *out_bytes);
 
 /* ---- batched encode (N independent streams) ---- */
 /* ec: nstreams controls, or one shared control when shared_control != 0.

@@ -15,10 +15,36 @@
 #define protected public
 #include "mp3enc.h"
 #include "mp3low.h"
+#include "srcc.h"
 #undef private
 #undef protected
 
 extern "C" {
+
+/* the reference's sample-format / sample-rate converter on its own (pins hmp3_amd/csrc/hx_src.cpp) */
+void *ref_src_new(void) { return new Csrc; }
+void ref_src_free(void *h) { delete (Csrc *) h; }
+int ref_src_init(void *h, int source, int channels, int bits, int is_float, int target, int target_channels, int *cutoff)
+{
+    return ((Csrc *) h)->sr_convert_init(source, channels, bits, is_float, target, target_channels, cutoff);
+}
+int ref_src_convert(void *h, unsigned char *xin, float *yout, int *out_bytes)
+{
+    IN_OUT x = ((Csrc *) h)->sr_convert(xin, yout);
+    *out_bytes = x.out_bytes;
+    return x.in_bytes;
+}
+/* CMp3Enc::MP3_audio_encode_init / MP3_audio_encode with every argument */
+int ref_init_mp3(void *h, E_CONTROL *ec, int bits, int is_float, int mpeg_select, int mono_convert)
+{
+    return ((CMp3Enc *) h)->MP3_audio_encode_init(ec, bits, is_float, mpeg_select, mono_convert);
+}
+int ref_encode_mp3(void *h, unsigned char *pcm, unsigned char *out, int *in_bytes)
+{
+    IN_OUT x = ((CMp3Enc *) h)->MP3_audio_encode(pcm, out);
+    *in_bytes = x.in_bytes;
+    return x.out_bytes;
+}
 
 void *ref_new(void) { return new CMp3Enc; }
 void ref_free(void *h) { delete (CMp3Enc *) h; }

@@ -41,10 +41,17 @@ CASES = {
     "cli_w64_cbr64_s24_44k": (917, 30001, 44100, 24, False, ["-B64"]),                # Sony Wave64 GUID chunks
     "cli_ext_vbr60_s24_48k": (918, 30007, 48000, 24, False, ["-V60"]),                # WAVE_FORMAT_EXTENSIBLE + a LIST chunk
     "cli_odd_cbr64_u8_mono_44k": (919, 30001, 44100, 8, False, ["-B64"]),             # odd data size: the pad byte counts
+    # sample-rate conversion in front of the encoder (Csrc cases 1-4; -A picks the encode rate)
+    "cli_src_11k_to_22k_s16": (920, 20001, 11025, False, True, ["-B32"]),                 # 1:2 up
+    "cli_src_8k_to_16k_u8_mono": (921, 20003, 8000, 8, False, ["-B24"]),                  # 1:2 up, mono, 8-bit
+    "cli_src_32k_to_44k_f32": (922, 30011, 32000, True, False, ["-A44100", "-V60"]),      # up by 441:320, linear
+    "cli_src_48k_to_24k_s24": (923, 40001, 48000, 24, True, ["-A2", "-B32"]),             # 2:1 down, one filter bank
+    "cli_src_44k_to_32k_s16": (924, 40003, 44100, False, True, ["-A32000", "-B64"]),      # 441:320 down, two stages
+    "cli_src_44k_to_22k_downmix": (925, 40007, 44100, False, False, ["-A22050", "-M3", "-V50"]),   # down + down-mix
 }
 CONTAINER = {"cli_rifx_cbr64_s16_44k": "rifx", "cli_rf64_vbr50_s16_48k": "rf64", "cli_w64_cbr64_s24_44k": "w64",
              "cli_ext_vbr60_s24_48k": "ext"}
-MONO = {"cli_odd_cbr64_u8_mono_44k", "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k", "cli_lsf_mono_cbr24_s16_16k"}
+MONO = {"cli_odd_cbr64_u8_mono_44k", "cli_src_8k_to_16k_u8_mono", "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k", "cli_lsf_mono_cbr24_s16_16k"}
 
 
 def write_container(path, kind, fmt_tag, nch, sr, bits, data):
