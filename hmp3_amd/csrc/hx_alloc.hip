@@ -140,7 +140,7 @@ struct alignas(16) AllocLds {
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SWEEP_LOAD, HCMD_SWEEP, HCMD_EMIT };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_EMIT };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \
@@ -366,43 +366,38 @@ __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int
     }
 }
 
-// Band lane (ch, sfb) passes the gain step g it wants measured (-1: none) and gets the band's
-// noise back in a register; sbeg / send are the lane's band limits, kept by the caller.
-__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int g, int sbeg, int send, int nlines0, int nlines1)
+// One sweep of the gain search for channel ch, run by one wave on its own (the master wave does
+// channel 0 while the helper wave does channel 1: gain pairs, terms and sums of the two channels live
+// in separate LDS arrays, so the waves never wait for each other inside a search).  Band lane i < 32
+// passes the gain step g it wants measured (-1: none) and gets the band's noise back in a register;
+// sbeg / send are the lane's band limits, kept by the caller.
+__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int ch, int g, int sbeg, int send, int nlines)
 {
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
     // and the line range that any evaluated band touches
     int lo = 576, hi = 0;
     bool bslow = false;
     PROF_T0();
-    {
-        const int bch = LANE >> 5, bi = LANE & 31;
-        if (bi < NB) {
-            const float ig = (g >= 0) ? L.look_34igain[g] : -1.0f;
-            L.gig[bch][bi] = ig;
-            L.gg[bch][bi] = (g >= 0) ? L.look_gain[g] : 0.0f;
-            if (g >= 0) { lo = sbeg; hi = send; bslow = noise_band_needs_pow(ig, L.x34max[bch][bi]); }
-        }
-        lo = -hx_wave_max(-lo);
-        hi = hx_wave_max(hi);
+    if (LANE < NB) {
+        const float ig = (g >= 0) ? L.look_34igain[g] : -1.0f;
+        L.gig[ch][LANE] = ig;
+        L.gg[ch][LANE] = (g >= 0) ? L.look_gain[g] : 0.0f;
+        if (g >= 0) { lo = sbeg; hi = send; bslow = noise_band_needs_pow(ig, L.x34max[ch][LANE]); }
     }
+    lo = -hx_wave_max(-lo);
+    hi = hx_wave_max(hi);
     SYNC();
     PROF_ACC(27);
-    const bool two = nlines1 > 0;       // channel 1's lines on the helper wave (a mono stream has none)
-    if (two) HELPER_POST2(HCMD_SWEEP, lo, min(nlines1, hi));
-    sweep_lines(L, R, 0, lo, min(nlines0, hi));
-    if (two) HELPER_JOIN();
+    const int nl = min(nlines, hi);
+    sweep_lines(L, R, ch, lo, nl);
     if (__any(bslow)) {     // some band reaches beyond the table: rare, redo its lines with pow()
-        for (int ch = 0; ch < 2; ch++) {
-            const int nl = min(ch ? nlines1 : nlines0, hi);
-            for (int j = lo + LANE; j < nl; j += 64) {
-                const int bnd = L.band_of_line[j];
-                const float igain = L.gig[ch][bnd];
-                bool fast;
-                if (igain >= 0.0f) {
-                    noise_term(L, igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j], &fast);
-                    if (!fast) L.term[ch][j] = noise_term_slow(igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j]);
-                }
+        for (int j = lo + LANE; j < nl; j += 64) {
+            const int bnd = L.band_of_line[j];
+            const float igain = L.gig[ch][bnd];
+            bool fast;
+            if (igain >= 0.0f) {
+                noise_term(L, igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j], &fast);
+                if (!fast) L.term[ch][j] = noise_term_slow(igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j]);
             }
         }
     }
@@ -410,8 +405,8 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     PROF_ACC(28);
     int noise = 0;
     if (g >= 0) {
-        const float sxx = band_sum(&L.term[LANE >> 5][sbeg], send - sbeg, 0.0f);
-        noise = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[LANE & 31];
+        const float sxx = band_sum(&L.term[ch][sbeg], send - sbeg, 0.0f);
+        noise = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[LANE];
     }
     SYNC();
     PROF_ACC(29);
@@ -636,10 +631,10 @@ __device__ void seek_initial(AllocLds &L, const AllocPrm *p)
     SYNC();
 }
 
-// reference bitallo3.cpp:1164-1296: all bands walk their gain step concurrently
-__device__ void seek_actual(AllocLds &L, const AllocPrm *p)
+// reference bitallo3.cpp:1164-1296: all bands of channel ch walk their gain step concurrently (lane = sfb)
+__device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
 {
-    const int ch = LANE >> 5, i = LANE & 31;
+    const int i = LANE;
     const bool band = i < p->nsf[ch];
     // per-lane state machine: mode 0 = idle/done, 1 = first measurement, 2 = walking down, 3 = walking up.
     // The lane's band data (target, limits, estimator feedback, result) stays in registers over the
@@ -656,14 +651,12 @@ __device__ void seek_actual(AllocLds &L, const AllocPrm *p)
         else { smin = L.gzero[ch][i] + 5; tnmin = L.Noise0[ch][i]; }
     }
     SweepRegs R;
-    const int nl0 = p->nbmax[0], nl1 = p->nbmax[1];
-    if (nl1 > 0) HELPER_POST(HCMD_SWEEP_LOAD, 0);
-    sweep_load(L, R, 0);
-    if (nl1 > 0) HELPER_JOIN();
+    const int nl = p->nbmax[ch];
+    sweep_load(L, R, ch);
     SYNC();
     while (__any(mode != 0)) {
         PROF_CNT(20);
-        const int noise = noise_sweep(L, R, (mode == 0) ? -1 : (mode == 1 ? s : t), sbeg, send, nl0, nl1);
+        const int noise = noise_sweep(L, R, ch, (mode == 0) ? -1 : (mode == 1 ? s : t), sbeg, send, nl);
         if (mode == 1) {
             const int dn = noise - NTarget;
             ntadj += (dn >> 3);
@@ -682,6 +675,17 @@ __device__ void seek_actual(AllocLds &L, const AllocPrm *p)
     }
     if (band) { L.gsf[ch][i] = smin; L.Noise[ch][i] = tnmin; L.NTadjust[ch][i] = ntadj; }
     if (i < NB) L.geval[ch][i] = -1;
+    SYNC();
+}
+
+// both channels: channel 1's whole search on the helper wave
+__device__ void seek_actual(AllocLds &L, const AllocPrm *p)
+{
+    const bool two = p->nbmax[1] > 0;
+    if (two) HELPER_POST(HCMD_SEEK, 0);
+    seek_actual_ch(L, p, 0);
+    if (two) HELPER_JOIN();
+    else if (LANE < NB) L.geval[1][LANE] = -1;
     SYNC();
 }
 
