@@ -44,6 +44,7 @@ EXPORTS = [
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
     "hx_src_create", "hx_src_destroy", "hx_src_init", "hx_src_convert",
     "hx_batch_submit_s16_device", "hx_batch_submit_f32_device", "hx_batch_wait", "hx_batch_set_gate",
+    "hx_batch_submit_s16_host", "hx_batch_submit_f32_host", "hx_batch_wait_host", "hx_pinned_alloc", "hx_pinned_free",
     "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host",
     "hx_xing_create", "hx_xing_destroy", "hx_xing_header", "hx_xing_toc", "hx_xing_update_info", "hx_xing_update_crc", "hx_xing_bitrate_index", "hx_batch_status",
     "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
@@ -107,6 +108,13 @@ def lib():
         L.hx_batch_submit_s16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_submit_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.hx_batch_submit_s16_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_batch_submit_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_batch_wait_host.argtypes = [C.c_void_p]
+        L.hx_pinned_alloc.argtypes = [C.c_longlong]
+        L.hx_pinned_alloc.restype = C.c_void_p
+        L.hx_pinned_free.argtypes = [C.c_void_p]
+        L.hx_pinned_free.restype = None
         L.hx_batch_set_gate.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_set_gate.restype = None
         L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
@@ -188,6 +196,15 @@ class Batch:
         r = lib().hx_batch_submit_s16_device(self.h, d_pcm_ptr, nframes, d_out_ptr, out_stride, d_out_bytes_ptr, stream)
         if r != 0:
             raise RuntimeError("hx_batch_submit_s16_device failed: " + last_error())
+
+    def submit_host(self, pcm_ptr, nframes, out_ptr, out_stride, out_bytes_ptr):
+        """pipelined host-buffer call (int16 PCM); outputs are valid after wait_host()"""
+        if lib().hx_batch_submit_s16_host(self.h, pcm_ptr, nframes, out_ptr, out_stride, out_bytes_ptr) != 0:
+            raise RuntimeError("hx_batch_submit_s16_host failed: " + last_error())
+
+    def wait_host(self):
+        if lib().hx_batch_wait_host(self.h) != 0:
+            raise RuntimeError("hx_batch_wait_host failed: " + last_error())
 
     def set_gate(self, percent):
         lib().hx_batch_set_gate(self.h, percent)

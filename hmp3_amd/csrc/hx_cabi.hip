@@ -80,6 +80,12 @@ struct hx_batch {
     hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};
     long long nsubmit = 0;
     bool inflight = false;
+    // hx_batch_submit_*_host: device staging for two calls in flight and the copy streams
+    void *hs_pcm[2] = {nullptr, nullptr}; unsigned char *hs_out[2] = {nullptr, nullptr}; int *hs_nb[2] = {nullptr, nullptr};
+    long long hs_pcm_cap = 0, hs_out_cap = 0;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr, s_host = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr}, ev_hfront[2] = {nullptr, nullptr};
+    long long nhost = 0;
     int *d_done = nullptr;              // streams retired by all k_alloc launches of this batch
     long long alloc_launches = 0;
     int gate_percent = 90;              // a submit's front end starts once this share of the previous call's streams is done
@@ -105,6 +111,17 @@ extern "C" void hx_batch_destroy(hx_batch *b)
                     b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
                     b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done};
     for (void *p : ptrs) if (p) hipFree(p);
+    for (int i = 0; i < 2; i++) {
+        if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]);
+        if (b->hs_out[i]) hipFree(b->hs_out[i]);
+        if (b->hs_nb[i]) hipFree(b->hs_nb[i]);
+        if (b->ev_h2d[i]) hipEventDestroy(b->ev_h2d[i]);
+        if (b->ev_d2h[i]) hipEventDestroy(b->ev_d2h[i]);
+        if (b->ev_hfront[i]) hipEventDestroy(b->ev_hfront[i]);
+    }
+    if (b->s_h2d) hipStreamDestroy(b->s_h2d);
+    if (b->s_d2h) hipStreamDestroy(b->s_d2h);
+    if (b->s_host) hipStreamDestroy(b->s_host);
     if (b->s_front) hipStreamDestroy(b->s_front);
     if (b->s_alloc) hipStreamDestroy(b->s_alloc);
     hipEvent_t evs[] = {b->ev_in, b->ev_front[0], b->ev_front[1], b->ev_alloc[0], b->ev_alloc[1]};
@@ -354,6 +371,84 @@ extern "C" int hx_batch_wait(hx_batch *b, void *stream)
     const int last = (int) ((b->nsubmit - 1) & 1);
     HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_front[last], 0));
     HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_alloc[last], 0));
+    return 0;
+}
+
+// ---- pipelined host-buffer calls ----
+// The PCM of call n+1 crosses PCIe while call n is encoded, and the bitstream of call n while call
+// n+1 is: two sets of device staging buffers, one stream per copy direction, events in between.
+// Truly asynchronous only with page-locked host memory (hx_pinned_alloc); with pageable memory the
+// copies fall back to staged, mostly synchronous transfers and the result is still correct.
+extern "C" void *hx_pinned_alloc(long long bytes)
+{
+    void *p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t) bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void hx_pinned_free(void *p) { if (p) hipHostFree(p); }
+
+static int submit_host(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
+{
+    if (!b) return -1;
+    HIPCHK(hipSetDevice(b->device));
+    const long long pbytes = (long long) b->S * nframes * 1152 * b->nchan * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
+    if (!b->s_h2d) {
+        HIPCHK(hipStreamCreateWithFlags(&b->s_h2d, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b->s_d2h, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b->s_host, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventCreateWithFlags(&b->ev_h2d[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b->ev_d2h[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b->ev_hfront[i], hipEventDisableTiming));
+            HIPCHK(hipMalloc((void **) &b->hs_nb[i], sizeof(int) * b->S));
+        }
+    }
+    if (pbytes > b->hs_pcm_cap || obytes > b->hs_out_cap) {     // (re)size the staging: drain first
+        HIPCHK(hipDeviceSynchronize());
+        for (int i = 0; i < 2; i++) {
+            if (pbytes > b->hs_pcm_cap) { if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]); HIPCHK(hipMalloc(&b->hs_pcm[i], (size_t) pbytes)); }
+            if (obytes > b->hs_out_cap) { if (b->hs_out[i]) hipFree(b->hs_out[i]); HIPCHK(hipMalloc((void **) &b->hs_out[i], (size_t) obytes)); }
+        }
+        if (pbytes > b->hs_pcm_cap) b->hs_pcm_cap = pbytes;
+        if (obytes > b->hs_out_cap) b->hs_out_cap = obytes;
+    }
+    const int k = (int) (b->nhost & 1);
+    if (b->nhost >= 2) {
+        HIPCHK(hipStreamWaitEvent(b->s_h2d, b->ev_hfront[k], 0));   // the front end of call n-2 has read this PCM buffer
+        HIPCHK(hipStreamWaitEvent(b->s_host, b->ev_d2h[k], 0));     // the bitstream of call n-2 has left this output buffer
+    }
+    HIPCHK(hipMemcpyAsync(b->hs_pcm[k], pcm, (size_t) pbytes, hipMemcpyHostToDevice, b->s_h2d));
+    HIPCHK(hipEventRecord(b->ev_h2d[k], b->s_h2d));
+    HIPCHK(hipStreamWaitEvent(b->s_host, b->ev_h2d[k], 0));
+    const int set = (int) (b->nsubmit & 1);
+    int r = encode_core(b, is_f32 ? nullptr : (const int16_t *) b->hs_pcm[k], is_f32 ? (const float *) b->hs_pcm[k] : nullptr, nframes,
+                        b->hs_out[k], out_stride, b->hs_nb[k], b->s_host, 1);
+    if (r) return r;
+    HIPCHK(hipEventRecord(b->ev_hfront[k], b->s_front));
+    HIPCHK(hipStreamWaitEvent(b->s_d2h, b->ev_alloc[set], 0));
+    HIPCHK(hipMemcpyAsync(out_bytes, b->hs_nb[k], sizeof(int) * b->S, hipMemcpyDeviceToHost, b->s_d2h));
+    HIPCHK(hipMemcpyAsync(out, b->hs_out[k], (size_t) obytes, hipMemcpyDeviceToHost, b->s_d2h));
+    HIPCHK(hipEventRecord(b->ev_d2h[k], b->s_d2h));
+    b->nhost++;
+    return 0;
+}
+
+extern "C" int hx_batch_submit_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
+{
+    return submit_host(b, pcm, 0, nframes, out, out_stride, out_bytes);
+}
+
+extern "C" int hx_batch_submit_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
+{
+    return submit_host(b, pcm, 1, nframes, out, out_stride, out_bytes);
+}
+
+// block until the outputs of every submitted host call are in host memory
+extern "C" int hx_batch_wait_host(hx_batch *b)
+{
+    if (!b) return -1;
+    HIPCHK(hipSetDevice(b->device));
+    if (b->s_d2h) { HIPCHK(hipStreamSynchronize(b->s_front)); HIPCHK(hipStreamSynchronize(b->s_d2h)); }
     return 0;
 }
 

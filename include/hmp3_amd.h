@@ -128,6 +128,14 @@ int hx_batch_wait(hx_batch *b, void *stream);
 /* a submit's front end is held back until this share (percent, default 90) of the previous call's streams has
    left the allocator kernel, so that it runs in that kernel's tail; 0 starts it at once */
 void hx_batch_set_gate(hx_batch *b, int percent);
+/* The same pipelining for host buffers: the PCM of call n+1 crosses PCIe while call n is encoded and the
+   bitstream of call n while call n+1 is.  pcm must stay unchanged, and out / out_bytes are undefined, until
+   hx_batch_wait_host returns.  Use page-locked memory (hx_pinned_alloc) for copies that really overlap. */
+int hx_batch_submit_s16_host(hx_batch *b, const int16_t *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes);
+int hx_batch_submit_f32_host(hx_batch *b, const float *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes);
+int hx_batch_wait_host(hx_batch *b);
+void *hx_pinned_alloc(long long bytes);
+void hx_pinned_free(void *p);
 /* optional packet outputs of the batched calls: d_packet [nstreams][nframes][frame_stride] bytes,
    d_packet_bytes [nstreams][nframes][2] (the reference's nbytes_out[2] of every call: {size, 0},
    or the sizes of the two back-to-back packets of an MPEG-2 call); frame_stride >= the packet

@@ -273,6 +273,43 @@ def test_pipelined_submit_equals_plain_calls_and_oracle():
         assert got["plain"][s] == oracle_bytes(kw, pcm[s], F * calls), "stream %d" % s
 
 
+def test_pipelined_host_calls_equal_plain_host_calls():
+    """hx_batch_submit_s16_host / hx_batch_wait_host with page-locked buffers: copies in both directions overlap the
+    encoding of the neighbouring calls; every byte must equal what plain host calls return"""
+    import torch
+    kw = dict(vbr_mnr=60)
+    S, F, calls = 96, 10, 5
+    pcm = np.stack([synth.stream_pcm(1200 + i, F * calls, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    b0 = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    want = [b0.encode_host(pcm[:, c * F * 1152:(c + 1) * F * 1152]) for c in range(calls)]
+    b0.close()
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    stride = b.out_stride(F)
+    h_pcm = [torch.from_numpy(np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])).pin_memory() for c in range(calls)]
+    h_out = [torch.zeros((S, stride), dtype=torch.uint8).pin_memory() for _ in range(calls)]
+    h_nb = [torch.zeros((S,), dtype=torch.int32).pin_memory() for _ in range(calls)]
+    for c in range(calls):
+        b.submit_host(h_pcm[c].data_ptr(), F, h_out[c].data_ptr(), stride, h_nb[c].data_ptr())
+    b.wait_host()
+    assert b.status() == 0
+    for c in range(calls):
+        o, n = h_out[c].numpy(), h_nb[c].numpy()
+        for s in range(S):
+            assert o[s, :n[s]].tobytes() == want[c][s], "call %d stream %d" % (c, s)
+    # pageable memory works too (the copies just do not overlap)
+    b2 = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    p_out = [np.zeros((S, stride), np.uint8) for _ in range(calls)]
+    p_nb = [np.zeros((S,), np.int32) for _ in range(calls)]
+    p_pcm = [np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152]) for c in range(calls)]
+    for c in range(calls):
+        b2.submit_host(p_pcm[c].ctypes.data, F, p_out[c].ctypes.data, stride, p_nb[c].ctypes.data)
+    b2.wait_host()
+    for c in range(calls):
+        for s in range(0, S, 7):
+            assert p_out[c][s, :p_nb[c][s]].tobytes() == want[c][s]
+    b.close(); b2.close()
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""
