@@ -319,6 +319,15 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     else hipLaunchKernelGGL(k_alloc, dim3(S), dim3(128), 0, qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
+    while (b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events
+        const auto old = b->pending.front();
+        if (hipEventQuery(old.second) != hipSuccess) break;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, old.first, old.second) == hipSuccess) { b->alloc_ms_sum += ms; b->alloc_calls++; }
+        hipEventDestroy(old.first);
+        hipEventDestroy(old.second);
+        b->pending.erase(b->pending.begin());
+    }
     if (pipelined) {
         HIPCHK(hipEventRecord(b->ev_alloc[set], qa));
         b->nsubmit++;
