@@ -219,10 +219,21 @@ struct Tagger {
     }
 };
 
+int encode_loaded(std::vector<Input> &in, const std::vector<const char *> &files, const Options &opt);
+
+bool mpeg_rate(int r) { return r == 32000 || r == 44100 || r == 48000 || r == 16000 || r == 22050 || r == 24000; }
+
 int encode_one_file(const char *fin, const char *fout, const Options &opt)
 {
     Input in;
     if (!load_input(fin, opt, &in)) return 1;
+    if (!opt.mpeg_select && mpeg_rate(in.wi.rate) && strcmp(fout, "-")) {
+        // No rate conversion and a seekable output: the file goes through the batched API as a batch of one
+        // (96 frames per call instead of one), which writes exactly what the frame-by-frame loop below writes.
+        std::vector<Input> one(1);
+        one[0] = std::move(in);
+        return encode_loaded(one, {fin, fout}, opt);
+    }
     hx_enc *enc = hx_enc_create(0);
     // bytes a call needs in the buffer (more than it consumes); with a sample-rate conversion a call consumes a varying amount
     const int init_bytes = enc ? hx_enc_MP3_audio_encode_init(enc, &in.ec, in.wi.bits, in.is_float, opt.mpeg_select, in.mono_convert) : 0;
@@ -302,11 +313,17 @@ int encode_batch(const std::vector<const char *> &files, const Options &opt)
 {
     const int S = (int) files.size() / 2;
     std::vector<Input> in(S);
+    for (int i = 0; i < S; i++) if (!load_input(files[2 * i], opt, &in[i])) return 1;
+    return encode_loaded(in, files, opt);
+}
+
+int encode_loaded(std::vector<Input> &in, const std::vector<const char *> &files, const Options &opt)
+{
+    const int S = (int) in.size();
     std::vector<HX_E_CONTROL> ctl(S);
     int nch = 0;
     size_t max_calls = 0;
     for (int i = 0; i < S; i++) {
-        if (!load_input(files[2 * i], opt, &in[i])) return 1;
         HX_E_CONTROL ec = in[i].ec;
         if (in[i].mono_convert) ec.mode = 3;
         const int c = ec.mode == 3 ? 1 : 2;
@@ -314,8 +331,7 @@ int encode_batch(const std::vector<const char *> &files, const Options &opt)
         nch = c;
         if (!hx_control_info(&ec, &in[i].ec_used, &in[i].head)) { fprintf(stderr, "\n ENCODER INIT FAIL (%s)\n", files[2 * i]); return 1; }
         ctl[i] = ec;
-        const int r = in[i].wi.rate;
-        if (opt.mpeg_select || (r != 32000 && r != 44100 && r != 48000 && r != 16000 && r != 22050 && r != 24000)) {
+        if (opt.mpeg_select || !mpeg_rate(in[i].wi.rate)) {
             fprintf(stderr, "\n -batch encodes files at their own MPEG sample rate; %s needs a rate conversion (use the single-file mode)\n", files[2 * i]);
             return 1;
         }
