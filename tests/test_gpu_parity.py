@@ -310,6 +310,63 @@ def test_pipelined_host_calls_equal_plain_host_calls():
     b.close(); b2.close()
 
 
+def random_control(rng):
+    """a random but accepted E_CONTROL: rate, mode, CBR/VBR, -HF, DC filter, short-block threshold, tuning knobs"""
+    sr = int(rng.choice([44100, 48000, 32000, 22050, 24000, 16000]))
+    lsf = sr < 32000
+    kw = dict(samprate=sr, mode=int(rng.choice([0, 1, 1, 3])))
+    if rng.random() < 0.5:
+        kw["bitrate"] = int(rng.choice([24, 32, 40, 48, 56, 64, 80] if lsf else [48, 56, 64, 80, 96, 112, 128, 160]))
+    else:
+        kw["vbr_mnr"] = int(rng.integers(0, 151))
+        if rng.random() < 0.3:
+            kw["vbr_br_limit"] = int(rng.choice([40, 64, 96, 160]))
+        if rng.random() < 0.3:
+            kw["vbr_delta_mnr"] = int(rng.integers(-40, 51))
+    if not lsf and rng.random() < 0.3:
+        kw["hf_flag"] = int(rng.choice([1, 3]))
+        kw["freq_limit"] = int(rng.choice([17000, 19000, 22000, 24000]))
+    if rng.random() < 0.2:
+        kw["filter_select"] = 1
+    if rng.random() < 0.3:
+        kw["short_block_threshold"] = int(rng.choice([0, 100, 400, 99999]))
+    if rng.random() < 0.2:
+        kw["freq_limit"] = int(rng.choice([6000, 9000, 14000]))
+    if rng.random() < 0.2:
+        kw["test1"] = int(rng.integers(0, 12))
+    if rng.random() < 0.15:
+        kw["quick"] = 1
+    return kw
+
+
+def test_random_configurations_against_the_oracle():
+    """60 random accepted controls (rates of both MPEG versions, mono / stereo / joint stereo, CBR / VBR, -HF modes,
+    DC filter, thresholds, tuning knobs), three streams each, through ragged calls"""
+    rng = np.random.default_rng(20240917)
+    done = 0
+    for trial in range(200):
+        kw = random_control(rng)
+        if not O.OracleEncoder(O.default_control(**kw)).ok():
+            continue        # out of scope for both (intensity stereo) or rejected by the reference
+        sr, mono = kw["samprate"], kw["mode"] == 3
+        S, F = 3, 22
+        pcm = np.stack([synth.stream_pcm(3000 + 7 * trial + i, F, sr=sr, rho=RHOS[(trial + i) % 4], bursts=True) for i in range(S)])
+        if mono:
+            pcm = np.ascontiguousarray(pcm[:, :, 0])
+        b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+        cut = int(rng.integers(1, F))
+        got = b.encode_host(pcm[:, :cut * 1152])
+        got2 = b.encode_host(pcm[:, cut * 1152:])
+        assert b.status() == 0, kw
+        for s in range(S):
+            assert got[s] + got2[s] == oracle_bytes(kw, pcm[s], F), (kw, s)
+        b.close()
+        done += 1
+        if done == 60:
+            break
+    assert done == 60
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""

@@ -187,3 +187,28 @@ def test_carried_state_matches_every_frame():
         # last granule's quantised spectrum and scalefactors
         assert np.array_equal(np.array(rd.ix), np.array(d.ix).reshape(2, 2, 576)[1].reshape(-1))
         assert np.array_equal(np.array(rd.sf_l).reshape(2, 2, 23)[:, :, :21], np.array(d.sf).reshape(2, 2, 22)[:, :, :21])
+
+
+def test_random_configurations_byte_identical():
+    """the random controls of tests/test_gpu_parity.py::test_random_configurations_against_the_oracle, oracle vs reference"""
+    from tests.test_gpu_parity import random_control
+    rng = np.random.default_rng(20240917)
+    done = 0
+    for trial in range(200):
+        kw = random_control(rng)
+        o = O.OracleEncoder(O.default_control(**kw))
+        if not o.ok():
+            continue
+        sr, mono = kw["samprate"], kw["mode"] == 3
+        pcm = synth.stream_pcm(3000 + 7 * trial, 22, sr=sr, rho=[0.7, 0.0, 1.0, 0.3][trial % 4], bursts=True)
+        r = O.RefEncoder(O.default_control(**kw))
+        if mono:
+            pcm = pcm[:, 0].copy()
+        a = b"".join(r.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(22))
+        b = b"".join(o.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(22))
+        assert a == b, kw
+        done += 1
+        if done == 60:
+            break
+    assert done == 60
+
