@@ -118,6 +118,31 @@ def test_packet_variant_matches_oracle(kw):
     e.close()
 
 
+SHIM_CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "hmp3_on_amd")
+
+
+@pytest.mark.skipif(not os.path.exists(SHIM_CLI), reason="oracle/_ref/hmp3_on_amd not built (make -C oracle shimcli)")
+@pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr75_f32_48k_hf", "cli_cbr192_s16_32k_x1_dc", "cli_vbr50_s24_44k",
+                                  "cli_mono_vbr60_f32_48k", "cli_downmix_vbr50_s16_44k", "cli_lsf_cbr64_s16_22k",
+                                  "cli_lsf_mono_cbr24_s16_16k", "cli_rf64_vbr50_s16_48k", "cli_src_11k_to_22k_s16",
+                                  "cli_src_44k_to_32k_s16", "cli_src_44k_to_22k_downmix"])
+def test_reference_cli_source_on_the_drop_in_library(name, tmp_path):
+    """The drop-in claim, exercised by the reference's own driver: its command line (test/tomp3.cpp with its WAV
+    parser and tag writer, compiled unmodified where it lies) built against include/shim/mp3enc.h and -lhmp3amd
+    must write the same files as the reference CLI built on the reference encoder (tests/golden/cli_*.mp3)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden_cli as M
+    seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
+    wav, mp3 = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3")
+    M.write_wav(wav, M.case_pcm(name), sr, as_float, M.CONTAINER.get(name))
+    r = subprocess.run([SHIM_CLI, wav, mp3] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()
+
+
 @pytest.mark.parametrize("which", ["mpeg1", "mpeg2"])
 def test_cli_batch_mode_files_byte_identical_to_reference_cli(tmp_path, which):
     """`hmp3amd -batch`: files of different rates / sample formats / lengths encoded as one batch of streams;
