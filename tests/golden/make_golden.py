@@ -1,7 +1,7 @@
 """Generate tests/golden/* from the REAL reference (oracle/_ref/libhmp3ref.so).
 Runs only in the build container (needs `make -C oracle ref`).  The fixtures are data:
 inputs are regenerated from seeds (hmp3_amd/synth.py, numpy PCG64), outputs are what the
-reference produced.  Usage: python tools/make_golden.py
+reference produced.  Usage: python tests/golden/make_golden.py
 """
 import ctypes as C
 import json
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O          # noqa: E402
 from hmp3_amd import synth              # noqa: E402

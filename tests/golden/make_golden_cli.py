@@ -1,7 +1,7 @@
 """File-level golden vectors for the CLI: WAVs synthesised by hmp3_amd/synth.py are
 encoded by the REAL reference CLI (oracle/_ref/hmp3, built by `make -C oracle ref`) and the complete
 .mp3 files (tag frame included) are committed under tests/golden/.  Run in the build container:
-    python tools/make_golden_cli.py
+    python tests/golden/make_golden_cli.py
 The WAVs themselves are not committed: tests regenerate them from the same seeds."""
 import json
 import os
@@ -12,7 +12,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hmp3_amd import synth  # noqa: E402
 

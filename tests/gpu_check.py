@@ -1,5 +1,5 @@
 """Stage-by-stage comparison of the HIP pipeline against the oracle on a real GPU.
-Usage: python tools/gpu_check.py [nstreams] [nframes] [config]
+Usage: python tests/gpu_check.py [nstreams] [nframes] [config]
 Prints the first stage / frame where the two differ (everything is expected to be bit-exact).
 """
 import sys, os, time

@@ -87,11 +87,11 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
                                   "cli_src_48k_to_24k_s24", "cli_src_44k_to_32k_s16", "cli_src_44k_to_22k_downmix"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
-    reference CLI (tests/golden/cli_*.mp3, tools/make_golden_cli.py)"""
+    reference CLI (tests/golden/cli_*.mp3, tests/golden/make_golden_cli.py)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
     import make_golden_cli as M
     seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
     wav, mp3 = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3")
@@ -133,7 +133,7 @@ def test_reference_cli_source_on_the_drop_in_library(name, tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
     import make_golden_cli as M
     seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
     wav, mp3 = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3")
@@ -150,7 +150,7 @@ def test_cli_batch_mode_files_byte_identical_to_reference_cli(tmp_path, which):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
     import make_golden_cli as M
     inputs, bflags = (M.BATCH_INPUTS, M.BATCH_FLAGS) if which == "mpeg1" else (M.BATCH_LSF_INPUTS, M.BATCH_LSF_FLAGS)
     args = []

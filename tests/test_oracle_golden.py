@@ -1,4 +1,4 @@
-"""The oracle (oracle/hxo_*.c) against the committed golden vectors that tools/make_golden.py
+"""The oracle (oracle/hxo_*.c) against the committed golden vectors that tests/golden/make_golden.py
 captured from the real reference.  CPU only."""
 import ctypes as C
 import json
