@@ -42,7 +42,7 @@ EXPORTS = [
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
-    "hx_src_create", "hx_src_destroy", "hx_src_init", "hx_src_convert",
+    "hx_batch_reset_stream", "hx_src_create", "hx_src_destroy", "hx_src_init", "hx_src_convert",
     "hx_batch_submit_s16_device", "hx_batch_submit_f32_device", "hx_batch_wait", "hx_batch_set_gate",
     "hx_batch_submit_s16_host", "hx_batch_submit_f32_host", "hx_batch_wait_host", "hx_pinned_alloc", "hx_pinned_free",
     "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host",
@@ -115,6 +115,7 @@ def lib():
         L.hx_pinned_alloc.restype = C.c_void_p
         L.hx_pinned_free.argtypes = [C.c_void_p]
         L.hx_pinned_free.restype = None
+        L.hx_batch_reset_stream.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_set_gate.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_set_gate.restype = None
         L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
@@ -205,6 +206,11 @@ class Batch:
     def wait_host(self):
         if lib().hx_batch_wait_host(self.h) != 0:
             raise RuntimeError("hx_batch_wait_host failed: " + last_error())
+
+    def reset_stream(self, i):
+        """slot i starts a new stream (same configuration)"""
+        if lib().hx_batch_reset_stream(self.h, i) != 0:
+            raise RuntimeError("hx_batch_reset_stream failed: " + last_error())
 
     def set_gate(self, percent):
         lib().hx_batch_set_gate(self.h, percent)

@@ -195,6 +195,24 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
 
 extern "C" int hx_batch_nstreams(const hx_batch *b) { return b ? b->S : 0; }
 
+// Start a new stream in slot i (same configuration as the slot's previous stream): the state a freshly created
+// batch would have for it - reservoir, histories, allocator feedback, subband carry - so a long-lived batch can
+// take over new inputs as old ones end.  Waits for the work in flight; the other streams are not touched.
+extern "C" int hx_batch_reset_stream(hx_batch *b, int i)
+{
+    if (!b || i < 0 || i >= b->S) { set_err("stream index out of range"); return -1; }
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    HxStream *st = new HxStream;
+    hx_stream_reset(&b->params[b->cls_of[i]], b->cls_of[i], st);
+    hipError_t e = hipMemcpy(b->d_st + i, st, sizeof(HxStream), hipMemcpyHostToDevice);
+    delete st;
+    if (e != hipSuccess) { set_err("HIP error: %s", hipGetErrorString(e)); return -1; }
+    const size_t per = (size_t) (2 * b->maxF + 3) * 576 * sizeof(float);     // subband slots of one (stream, channel)
+    HIPCHK(hipMemset((char *) b->d_sb + (size_t) i * 2 * per, 0, 2 * per));
+    return 0;
+}
+
 extern "C" long long hx_batch_out_stride(const hx_batch *b, int nframes)
 {
     // nframes new frames plus the images of the frames still pending from earlier calls (their

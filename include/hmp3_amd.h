@@ -97,6 +97,9 @@ int hx_src_convert(hx_src *s, const unsigned char *xin, float *yout, int *out_by
 hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTROL *ec, int shared_control, int max_frames);
 void hx_batch_destroy(hx_batch *b);
 int hx_batch_nstreams(const hx_batch *b);
+/* start a new stream in slot i with the slot's configuration (the state CMp3Enc::L3_audio_encode_init leaves,
+   mp3enc.cpp:278-287, 788-837); waits for work in flight, leaves the other streams alone */
+int hx_batch_reset_stream(hx_batch *b, int i);
 /* worst-case bytes one stream can emit in a call of nframes frames */
 long long hx_batch_out_stride(const hx_batch *b, int nframes);
 /* PCM: int16 interleaved L/R, [nstreams][nframes*1152][2]; out: [nstreams][out_stride] bytes;

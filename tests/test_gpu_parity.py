@@ -392,6 +392,30 @@ def test_random_configurations_against_the_oracle():
     assert done == 60
 
 
+def test_reset_stream_starts_a_fresh_stream_in_a_running_batch():
+    """hx_batch_reset_stream: a slot of a long-lived batch takes over a new input; its output equals a fresh encode
+    of that input, and the neighbouring streams carry on undisturbed"""
+    kws = [dict(bitrate=64), dict(vbr_mnr=70), dict(bitrate=64, samprate=48000)]
+    S, F = 6, 18
+    ctl = [api().default_control(**kws[i % 3]) for i in range(S)]
+    srs = [kws[i % 3].get("samprate", 44100) for i in range(S)]
+    first = np.stack([synth.stream_pcm(1500 + i, F, sr=srs[i], bursts=True) for i in range(S)])
+    second = np.stack([synth.stream_pcm(1600 + i, F, sr=srs[i], bursts=True) for i in range(S)])
+    b = api().Batch(ctl, nstreams=S, max_frames=F)
+    out1 = b.encode_host(first)
+    for i in (1, 2, 5):
+        b.reset_stream(i)
+    out2 = b.encode_host(second)
+    assert b.status() == 0
+    for i in range(S):
+        if i in (1, 2, 5):      # a new stream: as if encoded from scratch
+            assert out1[i] == oracle_bytes(kws[i % 3], first[i], F)
+            assert out2[i] == oracle_bytes(kws[i % 3], second[i], F), i
+        else:                   # an old stream: one continuous encode of both halves
+            assert out1[i] + out2[i] == oracle_bytes(kws[i % 3], np.concatenate([first[i], second[i]]), 2 * F), i
+    b.close()
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""
