@@ -42,7 +42,7 @@ EXPORTS = [
     "hx_enc_get_bitrate_float", "hx_enc_get_bitrate2_float", "hx_enc_get_frames",
     "hx_enc_get_frames_bytes", "hx_enc_info_ec", "hx_enc_info_head", "hx_enc_info_string",
     "hx_batch_create", "hx_batch_destroy", "hx_batch_nstreams", "hx_batch_out_stride",
-    "hx_batch_reset_stream", "hx_src_create", "hx_src_destroy", "hx_src_init", "hx_src_convert",
+    "hx_batch_reset_stream", "hx_batch_stream_state_bytes", "hx_batch_get_stream_state", "hx_batch_set_stream_state", "hx_src_create", "hx_src_destroy", "hx_src_init", "hx_src_convert",
     "hx_batch_submit_s16_device", "hx_batch_submit_f32_device", "hx_batch_wait", "hx_batch_set_gate",
     "hx_batch_submit_s16_host", "hx_batch_submit_f32_host", "hx_batch_wait_host", "hx_pinned_alloc", "hx_pinned_free",
     "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host",
@@ -116,6 +116,10 @@ def lib():
         L.hx_pinned_free.argtypes = [C.c_void_p]
         L.hx_pinned_free.restype = None
         L.hx_batch_reset_stream.argtypes = [C.c_void_p, C.c_int]
+        L.hx_batch_stream_state_bytes.argtypes = [C.c_void_p]
+        L.hx_batch_stream_state_bytes.restype = C.c_longlong
+        L.hx_batch_get_stream_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.hx_batch_set_stream_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hx_batch_set_gate.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_set_gate.restype = None
         L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
@@ -211,6 +215,18 @@ class Batch:
         """slot i starts a new stream (same configuration)"""
         if lib().hx_batch_reset_stream(self.h, i) != 0:
             raise RuntimeError("hx_batch_reset_stream failed: " + last_error())
+
+    def get_stream_state(self, i):
+        """checkpoint of stream i (bytes)"""
+        buf = (C.c_ubyte * int(lib().hx_batch_stream_state_bytes(self.h)))()
+        if lib().hx_batch_get_stream_state(self.h, i, buf) != 0:
+            raise RuntimeError("hx_batch_get_stream_state failed: " + last_error())
+        return bytes(buf)
+
+    def set_stream_state(self, i, state):
+        buf = (C.c_ubyte * len(state)).from_buffer_copy(state)
+        if lib().hx_batch_set_stream_state(self.h, i, buf) != 0:
+            raise RuntimeError("hx_batch_set_stream_state failed: " + last_error())
 
     def set_gate(self, percent):
         lib().hx_batch_set_gate(self.h, percent)

@@ -195,6 +195,35 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
 
 extern "C" int hx_batch_nstreams(const hx_batch *b) { return b ? b->S : 0; }
 
+// Checkpoint of one stream: its HxStream record followed by the three carried subband granules of each
+// channel.  With it a stream continues in another slot, another batch of the same configuration, another GPU or
+// after a restart exactly where it stopped (the reference's equivalent is a copy of the CMp3Enc object).
+extern "C" long long hx_batch_stream_state_bytes(const hx_batch *b) { (void) b; return (long long) (sizeof(HxStream) + 2 * 3 * 576 * sizeof(float)); }
+
+static int stream_state_copy(hx_batch *b, int i, void *host, bool save)
+{
+    if (!b || i < 0 || i >= b->S || !host) { set_err("bad arguments"); return -1; }
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    char *h = (char *) host;
+    const size_t per = (size_t) (2 * b->maxF + 3) * 576;        // floats per (stream, channel) in the subband buffer
+    if (save) {
+        HIPCHK(hipMemcpy(h, b->d_st + i, sizeof(HxStream), hipMemcpyDeviceToHost));
+        for (int c = 0; c < 2; c++)
+            HIPCHK(hipMemcpy(h + sizeof(HxStream) + (size_t) c * 3 * 576 * sizeof(float), b->d_sb + ((size_t) i * 2 + c) * per, 3 * 576 * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        HxStream st;
+        memcpy(&st, h, sizeof(HxStream));
+        st.cls = b->cls_of[i];      // the class index is the receiving batch's
+        HIPCHK(hipMemcpy(b->d_st + i, &st, sizeof(HxStream), hipMemcpyHostToDevice));
+        for (int c = 0; c < 2; c++)
+            HIPCHK(hipMemcpy(b->d_sb + ((size_t) i * 2 + c) * per, h + sizeof(HxStream) + (size_t) c * 3 * 576 * sizeof(float), 3 * 576 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+extern "C" int hx_batch_get_stream_state(hx_batch *b, int i, void *dst) { return stream_state_copy(b, i, dst, true); }
+extern "C" int hx_batch_set_stream_state(hx_batch *b, int i, const void *src) { return stream_state_copy(b, i, (void *) src, false); }
+
 // Start a new stream in slot i (same configuration as the slot's previous stream): the state a freshly created
 // batch would have for it - reservoir, histories, allocator feedback, subband carry - so a long-lived batch can
 // take over new inputs as old ones end.  Waits for the work in flight; the other streams are not touched.

@@ -100,6 +100,12 @@ int hx_batch_nstreams(const hx_batch *b);
 /* start a new stream in slot i with the slot's configuration (the state CMp3Enc::L3_audio_encode_init leaves,
    mp3enc.cpp:278-287, 788-837); waits for work in flight, leaves the other streams alone */
 int hx_batch_reset_stream(hx_batch *b, int i);
+/* checkpoint / resume of one stream (encoder state + subband carry, hx_batch_stream_state_bytes bytes): what is
+   saved from slot i continues, after hx_batch_set_stream_state, in any slot of any batch created with the same
+   control for that slot (any size, any max_frames) - another GPU or a later process included */
+long long hx_batch_stream_state_bytes(const hx_batch *b);
+int hx_batch_get_stream_state(hx_batch *b, int i, void *dst);
+int hx_batch_set_stream_state(hx_batch *b, int i, const void *src);
 /* worst-case bytes one stream can emit in a call of nframes frames */
 long long hx_batch_out_stride(const hx_batch *b, int nframes);
 /* PCM: int16 interleaved L/R, [nstreams][nframes*1152][2]; out: [nstreams][out_stride] bytes;

@@ -416,6 +416,30 @@ def test_reset_stream_starts_a_fresh_stream_in_a_running_batch():
     b.close()
 
 
+def test_stream_checkpoint_resumes_in_another_batch():
+    """hx_batch_get / set_stream_state: streams saved from one batch continue in other slots of a new batch (other
+    size, other max_frames) with the bitstream of an uninterrupted encode"""
+    kw = dict(vbr_mnr=55)
+    F1, F2 = 13, 17
+    pcm = np.stack([synth.stream_pcm(1700 + i, F1 + F2, rho=RHOS[i % 4], bursts=True) for i in range(4)])
+    b1 = api().Batch(api().default_control(**kw), nstreams=4, max_frames=F1)
+    out1 = b1.encode_host(pcm[:, :F1 * 1152])
+    saved = [b1.get_stream_state(i) for i in range(4)]
+    b1.close()
+    b2 = api().Batch(api().default_control(**kw), nstreams=6, max_frames=F2)
+    place = [5, 0, 3, 2]        # stream i of the old batch goes to slot place[i]
+    for i, slot in enumerate(place):
+        b2.set_stream_state(slot, saved[i])
+    pcm2 = np.zeros((6, F2 * 1152, 2), np.int16)
+    for i, slot in enumerate(place):
+        pcm2[slot] = pcm[i, F1 * 1152:]
+    out2 = b2.encode_host(pcm2)
+    assert b2.status() == 0
+    for i, slot in enumerate(place):
+        assert out1[i] + out2[slot] == oracle_bytes(kw, pcm[i], F1 + F2), i
+    b2.close()
+
+
 def test_float_input_and_dc_filter_mixed_batch():
     """fp32 PCM at int16 scale with non-integral samples (the L3_audio_encode form), half of the
     streams with the DC blocker on"""
