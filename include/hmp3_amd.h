@@ -162,7 +162,8 @@ int hx_batch_encode_f32_host_stats(hx_batch *b, const float *pcm, int nframes, u
    mp3enc.cpp:839-866), host only; 0 = configuration rejected */
 int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *head_out);
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
-   there).  0 = healthy.  Synchronises. */
+   there), 4 = the Huffman bits packed for a channel differ from the bits counted for it (an internal
+   consistency check of the two-wave packer).  0 = healthy.  Synchronises. */
 int hx_batch_status(hx_batch *b);
 /* total frames / bytes emitted so far by stream i (synchronises) */
 HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int stream_index);
