@@ -622,7 +622,8 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int e = lane + 64 * k;
-            if (e < 288) dst[e] = reinterpret_cast<const float4 *>(xl)[e];
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            if (e < 288) __builtin_nontemporal_store(reinterpret_cast<const f4v *>(xl)[e], reinterpret_cast<f4v *>(dst) + e);     // read once, a kernel later
         }
     }
     psy_unit(xl, p, gt, etab_out + sg * 128, thr_out + sg * 128, btype == 2, xtab, es);
