@@ -304,6 +304,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
                        long long out_stride, int *d_out_bytes, void *stream, int pipelined = 0)
 {
     if (!b || nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range"); return -1; }
+    if (!d_out || !d_out_bytes || (!d_pcm && !d_pcm32)) { set_err("null buffer"); return -1; }
+    if (out_stride < hx_batch_out_stride(b, nframes)) { set_err("out_stride is smaller than hx_batch_out_stride(b, nframes)"); return -1; }
     hipStream_t q = (hipStream_t) stream, qa = q;
     HIPCHK(hipSetDevice(b->device));
     int set = 0;

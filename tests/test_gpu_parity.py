@@ -641,7 +641,16 @@ def test_api_misuse_fails_loudly_and_leaves_the_batch_usable():
     pcm = np.stack([synth.stream_pcm(5, 8), synth.stream_pcm(6, 8)])
     with pytest.raises(RuntimeError):           # more frames than the batch was created for
         b.encode_host(pcm)
-    first = b.encode_host(pcm[:, :4 * 1152])    # the failed call consumed nothing
+    import torch
+    dev = torch.device("cuda:0")
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm[:, :4 * 1152])).to(dev)
+    d_out = torch.zeros((2, 4096), dtype=torch.uint8, device=dev)
+    d_nb = torch.zeros((2,), dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="out_stride"):      # an output buffer smaller than hx_batch_out_stride asks for
+        b.encode_device(d_pcm.data_ptr(), 4, d_out.data_ptr(), 256, d_nb.data_ptr(), None)
+    with pytest.raises(RuntimeError, match="null"):
+        b.encode_device(d_pcm.data_ptr(), 4, None, b.out_stride(4), d_nb.data_ptr(), None)
+    first = b.encode_host(pcm[:, :4 * 1152])    # the failed calls consumed nothing
     second = b.encode_host(pcm[:, 4 * 1152:])
     for s in range(2):
         assert first[s] + second[s] == oracle_bytes(dict(bitrate=64), pcm[s], 8)
