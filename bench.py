@@ -1,96 +1,178 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the batched MP3 encode hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-Workload (BASELINE.json configs[1]): 1024 independent stereo 44.1 kHz streams x 256 frames per
-step, CBR 128 kbps, long blocks only (short_block_threshold = 99999), joint stereo; int16 PCM
-resident in HBM when the timed region starts.  A step = one pass of the whole pipeline
+--gpus N > 1 without a torch.distributed environment starts N single-GPU worker processes itself
+(one rank per GPU, before anything in this process touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks it is given
+are used as they are.  A world size that differs from --gpus is an error.
+
+Workloads (BASELINE.json configs; per GPU, weak scaling):
+  2 (default)  1024 streams x 256 frames, 44.1 kHz stereo, CBR-128, long blocks only (SBT 99999)
+  3            4096 x 256, 44.1 kHz, VBR -V50, block switching, bursts in the signal
+  4            4096 x 128, 48 kHz, VBR -V100 -HF2 -F19000 (one GPU's share of 32768 streams)
+  5            4096 x 256, sample rate {32, 44.1, 48 kHz}[stream mod 3], CBR-128, inter-channel
+               correlation {0, 0.3, 0.7, 1}[stream mod 4] (one GPU's share of 8 x 4096)
+int16 PCM resident in HBM when the timed region starts.  A step = one pass of the whole pipeline
 (polyphase -> MDCT -> psy -> allocator/quantiser/Huffman -> bitstream + reservoir) over the batch;
-stream state is carried from step to step, so K steps encode K x 256 consecutive frames of every
-stream.  Streams shard over ranks with no collective (weak scaling: 1024 streams per GPU).
-Rank 0 prints ONE JSON line.
+stream state is carried from step to step, so K steps encode K x F consecutive frames of every
+stream.  Streams shard over ranks with no collective; RCCL carries the barrier and the
+max-over-ranks time only.  After the timed region rank 0 copies --verify streams (PCM and the last
+step's bitstream) to the host and compares them byte for byte with the CPU oracle run over the
+same W + K steps.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_IN_PER_FRAME = 1152 * 2 * 2          # int16 stereo
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
+# vector issue peak: 256 CUs x 4 SIMD-32, one wave64 vector instruction per 2 cycles and SIMD, 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+RHO_CYCLE = [0.7, 0.0, 1.0, 0.3]
 
 
-def pmc_traffic(kernel, S, F):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs, gfx950 correction applied as MI355X_MICROARCH.md prescribes); None
-    when no pass exists for this workload.  Counters cannot be read from inside the timed run."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_counters_bench_1024x256.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if d["workload"]["streams"] != S or d["workload"]["frames_per_step"] != F:
-            return None
-        return int(d["kernels"][kernel]["hbm_bytes_corrected"])
-    except (OSError, KeyError, ValueError):
-        return None
+def workload(cfg):
+    """-> dict(name, S, F, classes = [(control kwargs, sample rate)], rho list, bursts)"""
+    if cfg == 2:
+        return dict(name="batch=%d stereo 44.1kHz streams x %d frames per step per GPU, CBR-128, long blocks only, int16 PCM resident in HBM",
+                    S=1024, F=256, classes=[(dict(bitrate=64, short_block_threshold=99999), 44100)], rho=[0.7], bursts=False)
+    if cfg == 3:
+        return dict(name="batch=%d stereo 44.1kHz streams x %d frames per step per GPU, VBR -V50, psy model + block switching (bursts), int16 PCM resident in HBM",
+                    S=4096, F=256, classes=[(dict(), 44100)], rho=[0.7], bursts=True)
+    if cfg == 4:
+        return dict(name="batch=%d stereo 48kHz streams x %d frames per step per GPU (one GPU's share of 32768), VBR -V100 -HF2 -F19000, int16 PCM resident in HBM",
+                    S=4096, F=128, classes=[(dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), 48000)], rho=[0.7], bursts=True)
+    if cfg == 5:
+        return dict(name="batch=%d stereo streams x %d frames per step per GPU (one GPU's share of 8 x 4096), 32/44.1/48kHz by stream mod 3, CBR-128, "
+                         "inter-channel correlation {0.7,0,1,0.3} by stream mod 4, block switching, int16 PCM resident in HBM",
+                    S=4096, F=256, classes=[(dict(bitrate=64, samprate=32000), 32000), (dict(bitrate=64), 44100), (dict(bitrate=64, samprate=48000), 48000)],
+                    rho=RHO_CYCLE, bursts=True)
+    raise SystemExit("unknown --config %r" % cfg)
 
 
-def synth_batch_gpu(torch, nstreams, nframes, sr, dev, first_stream=0):
-    """Same signal family as hmp3_amd/synth.py (tones with AM + high-passed random walk,
-    R = 0.7 L + 0.3 R'), synthesised on the GPU; per-stream tone parameters from PCG64 with
-    seed 0x484D5033 + stream index, noise from torch's generator."""
+def pmc_profile(cfg, S, F):
+    """the committed rocprofv3 --pmc passes for this workload (profiles/), or None"""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters_*.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            w = d["workload"]
+            if w["streams"] == S and w["frames_per_step"] == F and int(w.get("config", 2)) == cfg:
+                best = (d, os.path.relpath(path, ROOT))     # the latest round's file wins
+        except (OSError, KeyError, ValueError):
+            pass
+    return best
+
+
+def synth_batch_gpu(torch, np, nstreams, nframes, srs, rhos, bursts, dev, first_stream=0):
+    """Same signal family as hmp3_amd/synth.py (tones with AM + high-passed random walk, R = rho L +
+    (1 - rho) R', optional decaying white bursts every 0.7 s), synthesised on the GPU; per-stream tone
+    parameters from PCG64 with seed 0x484D5033 + global stream index, noise from torch's generator.
+    srs / rhos: per-stream sample rate and inter-channel correlation."""
     n = nframes * 1152
-    f = np.empty((nstreams, 2, 12)); a = np.empty_like(f); fm = np.empty_like(f); ph = np.empty_like(f)
-    for i in range(nstreams):
-        rng = np.random.Generator(np.random.PCG64(0x484D5033 + first_stream + i))
-        for c in range(2):
-            f[i, c] = rng.uniform(60.0, 9000.0, 12); a[i, c] = rng.uniform(0.02, 0.15, 12)
-            fm[i, c] = rng.uniform(0.1, 2.0, 12); ph[i, c] = rng.uniform(0.0, 2 * np.pi, 12)
     out = torch.empty((nstreams, n, 2), dtype=torch.int16, device=dev)
     g = torch.Generator(device=dev)
     g.manual_seed(0x484D5033 + first_stream)
-    t = torch.arange(n, dtype=torch.float64, device=dev) / sr
     chunk = 64
-    for s0 in range(0, nstreams, chunk):
-        s1 = min(nstreams, s0 + chunk)
-        x = torch.zeros((s1 - s0, 2, n), dtype=torch.float64, device=dev)
-        tf = torch.tensor(f[s0:s1], device=dev); ta = torch.tensor(a[s0:s1], device=dev)
-        tfm = torch.tensor(fm[s0:s1], device=dev); tph = torch.tensor(ph[s0:s1], device=dev)
-        for k in range(12):
-            x += ta[:, :, k:k + 1] * (0.6 + 0.4 * torch.sin(2 * np.pi * tfm[:, :, k:k + 1] * t)) * \
-                torch.sin(2 * np.pi * tf[:, :, k:k + 1] * t + tph[:, :, k:k + 1])
-        w = torch.cumsum(torch.randn((s1 - s0, 2, n), dtype=torch.float64, device=dev, generator=g), dim=2)
-        w = w - torch.nn.functional.avg_pool1d(w, 65, stride=1, padding=32)
-        w = w / (w.abs().amax(dim=2, keepdim=True) + 1e-9)
-        x = x + 0.1 * w
-        x[:, 1] = 0.7 * x[:, 0] + 0.3 * x[:, 1]
-        x = x * (0.95 / x.abs().amax(dim=(1, 2), keepdim=True))
-        out[s0:s1] = torch.round(x * 32767.0).to(torch.int16).permute(0, 2, 1)
+    idx_all = np.arange(nstreams)
+    for sr in sorted(set(srs)):
+        sel = idx_all[np.asarray(srs) == sr]
+        t = torch.arange(n, dtype=torch.float64, device=dev) / sr
+        for c0 in range(0, len(sel), chunk):
+            ids = sel[c0:c0 + chunk]
+            m = len(ids)
+            f = np.empty((m, 2, 12)); a = np.empty_like(f); fm = np.empty_like(f); ph = np.empty_like(f)
+            for k, i in enumerate(ids):
+                rng = np.random.Generator(np.random.PCG64(0x484D5033 + first_stream + int(i)))
+                for c in range(2):
+                    f[k, c] = rng.uniform(60.0, 9000.0, 12); a[k, c] = rng.uniform(0.02, 0.15, 12)
+                    fm[k, c] = rng.uniform(0.1, 2.0, 12); ph[k, c] = rng.uniform(0.0, 2 * np.pi, 12)
+            x = torch.zeros((m, 2, n), dtype=torch.float64, device=dev)
+            tf = torch.tensor(f, device=dev); ta = torch.tensor(a, device=dev)
+            tfm = torch.tensor(fm, device=dev); tph = torch.tensor(ph, device=dev)
+            for k in range(12):
+                x += ta[:, :, k:k + 1] * (0.6 + 0.4 * torch.sin(2 * np.pi * tfm[:, :, k:k + 1] * t)) * \
+                    torch.sin(2 * np.pi * tf[:, :, k:k + 1] * t + tph[:, :, k:k + 1])
+            w = torch.cumsum(torch.randn((m, 2, n), dtype=torch.float64, device=dev, generator=g), dim=2)
+            w = w - torch.nn.functional.avg_pool1d(w, 65, stride=1, padding=32)
+            w = w / (w.abs().amax(dim=2, keepdim=True) + 1e-9)
+            x = x + 0.1 * w
+            if bursts:
+                period = int(0.7 * sr)
+                env = torch.exp(-torch.arange(2000, dtype=torch.float64, device=dev) / 200.0)
+                for s0 in range(period // 2, n - 2000, period):
+                    x[:, :, s0:s0 + 2000] += 0.5 * env * torch.randn((m, 2, 2000), dtype=torch.float64, device=dev, generator=g)
+            rho = torch.tensor([rhos[int(i)] for i in ids], dtype=torch.float64, device=dev).view(m, 1)
+            x[:, 1] = rho * x[:, 0] + (1.0 - rho) * x[:, 1]
+            x = x * (0.95 / x.abs().amax(dim=(1, 2), keepdim=True))
+            out[torch.as_tensor(ids, device=dev)] = torch.round(x * 32767.0).to(torch.int16).permute(0, 2, 1)
     return out
+
+
+# ---- CPU side: the checker (oracle/) as verifier and as the reported CPU baseline -------------
+
+def _verify_worker(args):
+    """one process: the oracle's bitstream for the last `nlast` calls of `steps` passes over pcm"""
+    kw, pcm, steps, nlast = args
+    from oracle import oracle as O
+    import numpy as np
+    enc = O.OracleEncoder(O.default_control(**kw))
+    F = pcm.shape[0] // 1152
+    tail = []
+    for st in range(steps):
+        for f in range(F):
+            b = enc.encode_s16(pcm[f * 1152:(f + 1) * 1152])
+            if st * F + f >= steps * F - nlast:
+                tail.append(b)
+    return b"".join(tail)
+
+
+def verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, steps_total):
+    """byte-compare the last step's output of streams `ids` with the oracle; returns (n_ok, first bad id)"""
+    import multiprocessing as mp
+    F = wl["F"]
+    host_pcm = pcm[torch.as_tensor(ids, device=pcm.device)].cpu().numpy()
+    host_out = out[torch.as_tensor(ids, device=out.device)].cpu().numpy()
+    host_nb = nbytes.cpu().numpy()
+    jobs = [(kws[i], host_pcm[k], steps_total, F) for k, i in enumerate(ids)]
+    with mp.get_context("spawn").Pool(max(1, min(len(ids), os.cpu_count() or 1, 16))) as pool:
+        want = pool.map(_verify_worker, jobs)
+    ok, bad = 0, None
+    for k, i in enumerate(ids):
+        got = host_out[k, :host_nb[i]].tobytes()
+        if got == want[k]:
+            ok += 1
+        elif bad is None:
+            bad = int(i)
+    return ok, bad
 
 
 def _cpu_worker(args):
     """one process: encode `nframes` frames of a synthetic stream with the CPU checker"""
-    kind, nframes, seed = args
+    kind, nframes, seed, kw, sr, bursts = args
+    import numpy as np
     from oracle import oracle as O
     from hmp3_amd import synth
-    base = synth.stream_pcm(seed, 256)
+    base = synth.stream_pcm(seed, 256, sr=sr, bursts=bursts)
     reps = (nframes + 255) // 256
     pcm = np.ascontiguousarray(np.tile(base, (reps, 1))[: nframes * 1152])
-    ec = O.default_control(bitrate=64, short_block_threshold=99999)
+    ec = O.default_control(**kw)
     if kind == "reference":
         r = O.ref()
         h = r.ref_new()
         r.ref_init_s16(h, C.byref(ec))
-        out = (C.c_ubyte * (1 << 20))()
+        out = (C.c_ubyte * (4 << 20))()
         t0 = time.perf_counter()
         r.ref_encode_stream_s16(h, pcm.ctypes.data, nframes, out, len(out))
         dt = time.perf_counter() - t0
@@ -106,7 +188,7 @@ def _cpu_worker(args):
     return nframes, dt
 
 
-def cpu_baseline():
+def cpu_baseline(wl):
     """the reference built under oracle/_ref (kind "reference") or the oracle restatement
     (kind "port"), one process per host core, on a bounded sample of the same workload"""
     try:
@@ -117,17 +199,49 @@ def cpu_baseline():
     except Exception as e:      # no checker available on this box
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "none", "sample": "unavailable: %s" % e}
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    host = os.cpu_count() or 1
+    cores = max(1, min(host, 32))
     per = 24576 if kind == "reference" else 8192      # ~2-3 s of work per core
+    ncls = len(wl["classes"])
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(kind, per, i) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(kind, per, i, wl["classes"][i % ncls][0], wl["classes"][i % ncls][1], wl["bursts"]) for i in range(cores)])
     wall = time.perf_counter() - t0
     frames = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
-    return {"value": round(frames / busy, 1), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": "%d processes x %d frames of 44.1 kHz stereo CBR-128 long-block streams (%.1f s wall incl. spawn)" % (cores, per, wall),
+    return {"value": round(frames / busy, 1), "unit": "frames/s", "cores": cores, "host_cpu_count": host, "kind": kind,
+            "sample": "%d processes (of %d host CPUs) x %d frames of this workload's stream classes, one stream each (%.1f s wall incl. spawn)" % (cores, host, per, wall),
             "per_core": round(frames / busy / cores, 1)}
+
+
+# ---- launcher: --gpus N without a torch.distributed environment --------------------------------
+
+def launch_ranks(n, argv):
+    """start n single-GPU worker processes of this script (rank i on GPU i) and wait for them.
+    Nothing in this process has touched the GPU (torch is not even imported)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0:
+                    rc = rc or r
+                    for q in procs:         # a rank failed: the others would wait for it in the barrier
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
 
 
 def main():
@@ -135,102 +249,197 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=256, help="frames per stream per step")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[n-1]")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the config's)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: the config's)")
+    ap.add_argument("--verify", type=int, default=16, help="streams checked against the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed pass on the correlation-cycled signal set (config 2, one GPU)")
     ap.add_argument("--no-pipeline", action="store_true", help="plain hx_batch_encode_s16_device calls instead of submit / wait")
-    ap.add_argument("--gate", type=int, default=-1, help="hx_batch_set_gate percent (library default 90)")
+    ap.add_argument("--gate", type=int, default=-1, help="hx_batch_set_gate percent (library default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the barrier / max-time (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on GPU 0 (tests on a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous, sharding and reporting only, no encode (CPU test of the multi-rank path)")
     args = ap.parse_args()
-
-    import torch
-    from hmp3_amd import api
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
+    from hmp3_amd import shard
+    wl = workload(args.config)
+    S = args.streams or wl["S"]
+    F = args.frames or wl["F"]
+    first, last = shard.shard_range(S * world, world, rank)     # weak scaling: S streams per GPU, contiguous block per rank
+    assert last - first == S
+    ncls = len(wl["classes"])
+    kws = [wl["classes"][(first + i) % ncls][0] for i in range(S)]
+    srs = [wl["classes"][(first + i) % ncls][1] for i in range(S)]
+    rhos = [wl["rho"][(first + i) % len(wl["rho"])] for i in range(S)]
+
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")     # RCCL; used for the barrier and the max-over-ranks time only
-
-    S, F = args.streams, args.frames
-    sr = 44100
-    ec = api.default_control(bitrate=64, short_block_threshold=99999)
-    batch = api.Batch(ec, nstreams=S, max_frames=F, device=local)
-    if args.gate >= 0:
-        batch.set_gate(args.gate)
-    pcm = synth_batch_gpu(torch, S, F, sr, dev, first_stream=rank * S)
-    stride = batch.out_stride(F)
-    out = torch.empty((S, stride), dtype=torch.uint8, device=dev)
-    nbytes = torch.zeros((S,), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        # hx_batch_submit_s16_device: the front-end kernels of step n+1 run in the tail of step n's allocator kernel
-        # (its slowest streams), on the SIMDs the finished streams have left; all of every step's work completes
-        # inside the timed region (hx_batch_wait + synchronize in barrier()).  --no-pipeline: plain calls.
-        if not args.no_pipeline:
-            batch.submit_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
-        else:
-            batch.encode_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
-
-    def barrier():
-        batch.wait(stream)
-        torch.cuda.synchronize()
+    if args.dry_run:
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.init_process_group(args.backend)
+            t = torch.tensor([1.0 + rank], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seen = torch.zeros(world, dtype=torch.int64); seen[rank] = last - first
+            dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        else:
+            t = torch.tensor([1.0]); seen = torch.tensor([S])
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int((seen > 0).sum()), "streams_total": int(seen.sum()),
+                              "max_time_token": float(t.item()), "config": {"workload": wl["name"] % (S, F)}}), flush=True)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    batch.alloc_kernel_ms()             # drop warm-up timings
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    from hmp3_amd import api
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
+    if args.share_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    status = batch.status()
-    k_ms, k_calls = batch.alloc_kernel_ms()
-    out_total = int(nbytes.sum().item())
+        dist.init_process_group(args.backend)     # RCCL; used for the barrier and the max-over-ranks time only
+
+    def run(pcm, verify_n):
+        """warm-up + timed steps over one signal set with a fresh batch; returns measurements"""
+        ctl = api.default_control(**kws[0]) if ncls == 1 else [api.default_control(**k) for k in kws]
+        batch = api.Batch(ctl, nstreams=S, max_frames=F, device=local)
+        if args.gate >= 0:
+            batch.set_gate(args.gate)
+        stride = batch.out_stride(F)
+        out = torch.empty((S, stride), dtype=torch.uint8, device=dev)
+        nbytes = torch.zeros((S,), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def step():
+            # hx_batch_submit_s16_device: the front-end kernels of step n+1 run in the tail of step n's allocator kernel
+            # (its slowest streams); all of every step's work completes inside the timed region (hx_batch_wait +
+            # synchronize in barrier()).  --no-pipeline: plain calls.
+            if not args.no_pipeline:
+                batch.submit_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
+            else:
+                batch.encode_device(pcm.data_ptr(), F, out.data_ptr(), stride, nbytes.data_ptr(), stream)
+
+        def barrier():
+            batch.wait(stream)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        batch.alloc_kernel_ms()             # drop warm-up timings
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        m = {"dt": dt, "status": batch.status(), "out_total": int(nbytes.sum().item())}
+        m["k_ms"], m["k_calls"] = batch.alloc_kernel_ms()
+        m["gate_timeouts"] = batch.gate_timeouts() if hasattr(batch, "gate_timeouts") else 0
+        if verify_n > 0 and rank == 0:
+            rs = np.random.RandomState(12345 + args.config)
+            ids = sorted(rs.choice(S, size=min(verify_n, S), replace=False).tolist())
+            ok, bad = verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, args.warmup + args.steps)
+            m["verified"], m["verify_bad"], m["verify_n"] = ok, bad, len(ids)
+        batch.close()
+        del out, nbytes
+        return m
+
+    pcm = synth_batch_gpu(torch, np, S, F, srs, rhos, wl["bursts"], dev, first_stream=first)
+    m = run(pcm, args.verify)
+    worst = None
+    if args.config == 2 and world == 1 and not args.no_worst_case:
+        # the same config on the least friendly signal mix of the family: correlation cycled over {0.7, 0, 1, 0.3}
+        del pcm
+        pcm = synth_batch_gpu(torch, np, S, F, srs, [RHO_CYCLE[i % 4] for i in range(S)], wl["bursts"], dev, first_stream=first)
+        worst = run(pcm, 0)
+    del pcm
 
     if rank == 0:
         frames = S * F * args.steps * world
-        fps = frames / dt
-        out_per_frame = out_total / float(S * F)
-        alg_bytes = (BYTES_IN_PER_FRAME + out_per_frame) * S * F        # per launch of the dominant kernel
+        fps = frames / m["dt"]
+        k_ms, k_calls = m["k_ms"], m["k_calls"]
+        out_per_frame = m["out_total"] / float(S * F)
+        bytes_in = 1152 * 2 * 2                                          # int16 stereo
+        alg_bytes = (bytes_in + out_per_frame) * S * F                   # per launch of the dominant kernel
         ach = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-        traffic = pmc_traffic("k_alloc", S, F)
+        prof = pmc_profile(args.config, S, F)
+        kernel = "k_alloc" if srs[0] >= 32000 else "k_alloc_lsf"
+        traffic = None
+        valu = None
+        if prof is not None:
+            kc = prof[0]["kernels"].get(kernel, {})
+            if "hbm_bytes_corrected" in kc:
+                traffic = int(kc["hbm_bytes_corrected"])
+            if "SQ_INSTS_VALU" in kc and k_ms > 0:
+                # vector instructions the kernel issues per launch (committed SQ counters of this workload) over its
+                # live-measured duration, against the chip's vector issue rate
+                gi = kc["SQ_INSTS_VALU"] / (k_ms * 1e-3) / 1e9
+                valu = {"bound": "valu_issue", "kernel": kernel, "achieved": round(gi, 2), "peak": VALU_PEAK_GINST, "unit": "Ginst/s (wave64 vector instructions)",
+                        "frac": round(gi / VALU_PEAK_GINST, 4), "insts_per_launch": int(kc["SQ_INSTS_VALU"]),
+                        "waves_per_simd": round(kc.get("SQ_WAVES", 0) / 1024.0, 2),
+                        "lds_bank_conflict_frac": round(kc["SQ_LDS_BANK_CONFLICT"] / kc["SQ_LDS_IDX_ACTIVE"], 4) if kc.get("SQ_LDS_IDX_ACTIVE") else None,
+                        "valu_active_over_wave_cycles": round(kc["SQ_ACTIVE_INST_VALU"] / kc["SQ_WAVE_CYCLES"], 4) if kc.get("SQ_WAVE_CYCLES") else None,
+                        "counters": prof[1]}
+        sr0 = srs[0]
+        rt = sum(1152.0 / sr for sr in srs) / S                           # mean seconds of audio per frame
         res = {
-            "metric": "batched stereo 44.1kHz frames/sec (whole node), CBR-128",
+            "metric": "batched stereo 44.1kHz frames/sec (whole node), CBR-128" if args.config == 2 else "batched stereo frames/sec (whole node), BASELINE config %d" % args.config,
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(m["dt"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch=%d stereo 44.1kHz streams x %d frames per step per GPU, CBR-128, long blocks only, int16 PCM resident in HBM" % (S, F),
+            "config": {"workload": wl["name"] % (S, F), "baseline_config": args.config,
                        "streams_per_gpu": S, "frames_per_step": F, "parallelism": "streams sharded over %d GPU(s), no collective" % world},
-            "x_realtime_per_gpu": round(fps / world * 1152.0 / sr, 1),
-            "kernel_status": status,
+            "x_realtime_per_gpu": round(fps / world * rt, 1),
+            "kernel_status": m["status"], "gate_timeouts": m["gate_timeouts"],
             "bitstream_bytes_per_frame": round(out_per_frame, 2),
-            "roofline": {"bound": "hbm", "kernel": "k_alloc", "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6) if ach else None, "traffic": traffic,
                          "kernel_ms": round(k_ms, 3), "launches": k_calls,
-                         "algorithmic_bytes_per_frame": round(BYTES_IN_PER_FRAME + out_per_frame, 1)},
+                         "algorithmic_bytes_per_frame": round(bytes_in + out_per_frame, 1)},
         }
+        if valu is not None:
+            res["roofline_issue"] = valu
+        if "verified" in m:
+            res["verified_streams"] = m["verified"]
+            res["verify"] = {"checked": m["verify_n"], "identical": m["verified"], "first_mismatch": m["verify_bad"],
+                             "what": "last step's bitstream of randomly chosen streams vs the CPU oracle run over the same %d steps" % (args.warmup + args.steps)}
+        if worst is not None:
+            res["worst_case_value"] = round(S * F * args.steps / worst["dt"], 1)
+            res["worst_case"] = {"signal": "inter-channel correlation cycled over {0.7, 0, 1, 0.3} by stream", "ms_per_step": round(worst["dt"] / args.steps * 1e3, 3),
+                                 "kernel_ms": round(worst["k_ms"], 3), "kernel_status": worst["status"]}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(res), flush=True)
+        failed = m["status"] != 0 or ("verified" in m and m["verified"] != m["verify_n"])
+    else:
+        failed = False
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    batch.close()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

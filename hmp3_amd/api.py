@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhmp3amd.so")
+# HMP3AMD_LIB selects another build of the same library (tools/: the -DHX_PROFILE build)
+LIB_PATH = os.environ.get("HMP3AMD_LIB") or os.path.join(HERE, "libhmp3amd.so")
 
 
 class EControl(C.Structure):
@@ -47,6 +48,8 @@ EXPORTS = [
     "hx_batch_submit_s16_host", "hx_batch_submit_f32_host", "hx_batch_wait_host", "hx_pinned_alloc", "hx_pinned_free",
     "hx_batch_encode_s16_device", "hx_batch_encode_s16_host", "hx_batch_encode_f32_device", "hx_batch_encode_f32_host",
     "hx_xing_create", "hx_xing_destroy", "hx_xing_header", "hx_xing_toc", "hx_xing_update_info", "hx_xing_update_crc", "hx_xing_bitrate_index", "hx_batch_status",
+    "hx_batch_gate_timeouts", "hx_enc_out_stats", "hx_multi_create", "hx_multi_destroy", "hx_multi_ndevices", "hx_multi_nstreams", "hx_multi_shard", "hx_multi_batch",
+    "hx_multi_out_stride", "hx_multi_encode_s16_host", "hx_multi_encode_f32_host", "hx_multi_encode_f32_host_stats", "hx_multi_status",
     "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
 ]
 
@@ -125,6 +128,21 @@ def lib():
         L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
         L.hx_batch_status.argtypes = [C.c_void_p]
+        L.hx_batch_gate_timeouts.argtypes = [C.c_void_p]
+        L.hx_multi_create.restype = C.c_void_p
+        L.hx_multi_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.hx_multi_destroy.argtypes = [C.c_void_p]
+        L.hx_multi_ndevices.argtypes = [C.c_void_p]
+        L.hx_multi_nstreams.argtypes = [C.c_void_p]
+        L.hx_multi_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hx_multi_batch.restype = C.c_void_p
+        L.hx_multi_batch.argtypes = [C.c_void_p, C.c_int]
+        L.hx_multi_out_stride.restype = C.c_longlong
+        L.hx_multi_out_stride.argtypes = [C.c_void_p, C.c_int]
+        L.hx_multi_encode_s16_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_multi_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.hx_multi_encode_f32_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.hx_multi_status.argtypes = [C.c_void_p]
         L.hx_batch_frames_bytes.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_frames_bytes.restype = IntPair
         L.hx_batch_alloc_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -224,6 +242,9 @@ class Batch:
         return bytes(buf)
 
     def set_stream_state(self, i, state):
+        need = int(lib().hx_batch_stream_state_bytes(self.h))
+        if len(state) != need:
+            raise ValueError("stream state blob has %d bytes, this library's has %d" % (len(state), need))
         buf = (C.c_ubyte * len(state)).from_buffer_copy(state)
         if lib().hx_batch_set_stream_state(self.h, i, buf) != 0:
             raise RuntimeError("hx_batch_set_stream_state failed: " + last_error())
@@ -237,6 +258,9 @@ class Batch:
 
     def status(self):
         return int(lib().hx_batch_status(self.h))
+
+    def gate_timeouts(self):
+        return int(lib().hx_batch_gate_timeouts(self.h))
 
     def frames_bytes(self, i):
         p = lib().hx_batch_frames_bytes(self.h, i)
@@ -260,6 +284,59 @@ class Batch:
     def close(self):
         if self.h:
             lib().hx_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """nstreams streams over several GPUs of one node (hx_multi_*): contiguous blocks, one host thread per device"""
+
+    def __init__(self, controls, nstreams=None, max_frames=256, ndev=0, devices=None):
+        L = lib()
+        dv = (C.c_int * len(devices))(*devices) if devices else None
+        if isinstance(controls, EControl):
+            self.n = int(nstreams)
+            self._ec = controls
+            self.h = L.hx_multi_create(ndev, dv, self.n, C.byref(controls), 1, max_frames)
+        else:
+            self.n = len(controls)
+            self._ec = (EControl * self.n)(*controls)
+            self.h = L.hx_multi_create(ndev, dv, self.n, self._ec, 0, max_frames)
+        if not self.h:
+            raise RuntimeError("hx_multi_create failed: " + last_error())
+
+    def ndevices(self):
+        return int(lib().hx_multi_ndevices(self.h))
+
+    def shard(self, k):
+        d, f, c = C.c_int(), C.c_int(), C.c_int()
+        if lib().hx_multi_shard(self.h, k, C.byref(d), C.byref(f), C.byref(c)) != 0:
+            raise IndexError(k)
+        return d.value, f.value, c.value
+
+    def encode_host(self, pcm):
+        f32 = np.asarray(pcm).dtype == np.float32
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32 if f32 else np.int16)
+        nfr = pcm.shape[1] // 1152
+        stride = int(lib().hx_multi_out_stride(self.h, nfr))
+        out = np.zeros((self.n, stride), dtype=np.uint8)
+        nb = np.zeros(self.n, dtype=np.int32)
+        fn = lib().hx_multi_encode_f32_host if f32 else lib().hx_multi_encode_s16_host
+        if fn(self.h, pcm.ctypes.data, nfr, out.ctypes.data, stride, nb.ctypes.data) != 0:
+            raise RuntimeError("hx_multi_encode host call failed: " + last_error())
+        return [out[i, :nb[i]].tobytes() for i in range(self.n)]
+
+    def status(self):
+        return int(lib().hx_multi_status(self.h))
+
+    def close(self):
+        if self.h:
+            lib().hx_multi_destroy(self.h)
             self.h = None
 
     def __del__(self):

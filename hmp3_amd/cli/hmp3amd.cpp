@@ -22,7 +22,7 @@
 namespace {
 
 struct WavInfo { int channels = 0, rate = 0, bits = 0, type = 0, bigendian = 0; uint64_t data_bytes = 0; };
-struct Options { HX_E_CONTROL ec; int xing_flag = 3 | 0x40, ignore_length = 0, mpeg_select = 0; };
+struct Options { HX_E_CONTROL ec; int xing_flag = 3 | 0x40, ignore_length = 0, mpeg_select = 0, ec_display = 0, ngpus = 0; };
 
 // a header field of n bytes in the file's byte order
 uint64_t field(const unsigned char *p, int n, int be)
@@ -127,7 +127,8 @@ void usage()
             "\n   -Mn  0 stereo, 1 joint stereo, 3 mono      -Fn  low-pass Hz      -HFn high-frequency mode"
             "\n   -SBTn short-block threshold      -S1  DC blocker       -Xn  0 no tag, 1 Xing, 2/3 + TOC, default + info"
             "\n   -Cn -On copyright / original bits   -Ln VBR bitrate cap   -Tn -TXn tuning   -IL ignore the WAV length field"
-            "\n   -An  encode rate: 0 track the input (default), 1 an MPEG-1 rate, 2 an MPEG-2 rate, else that rate in Hz\n");
+            "\n   -An  encode rate: 0 track the input (default), 1 an MPEG-1 rate, 2 an MPEG-2 rate, else that rate in Hz"
+            "\n   -EC  print the encoder settings in use    -D  no progress display    -Gn  GPUs used by -batch (default all)\n");
 }
 
 // one input file, read and checked
@@ -147,16 +148,20 @@ struct Input {
     void pad(int init_bytes) { size = audio_bytes + 4 * (size_t) init_bytes; data.resize(size + (1 << 17), 0); }
 };
 
-bool load_input(const char *path, const Options &opt, Input *in)
+// open the input, parse and check its header; on success *fp is positioned at the first audio byte and
+// *indatasize is the number of audio bytes to read (UINT64_MAX: until the end of the file)
+bool open_input(const char *path, const Options &opt, Input *in, FILE **fp, uint64_t *indatasize_out)
 {
     FILE *f = strcmp(path, "-") ? fopen(path, "rb") : stdin;
     if (!f) { fprintf(stderr, "\n CANNOT_OPEN_INPUT_FILE %s\n", path); return false; }
+    *fp = f;
     const int ignore_length = opt.ignore_length || f == stdin;
     if (!wav_header(f, &in->wi)) { fprintf(stderr, "\n UNRECOGNIZED PCM FILE TYPE\n"); return false; }
     const WavInfo &wi = in->wi;
     // a data size of 0xFFFFFFFF means "until the end of the file" (tomp3.cpp:751-768)
     const uint64_t indatasize = (ignore_length || wi.data_bytes == 0xFFFFFFFFu) ? UINT64_MAX : wi.data_bytes;
     if (indatasize == 0) { fprintf(stderr, "\n INPUT FILE CONTAINS NO AUDIO\n"); return false; }
+    *indatasize_out = indatasize;
     fprintf(stderr, "\n pcm file:  channels = %d  bits = %d,  rate = %d  type = %d", wi.channels, wi.bits, wi.rate, wi.type);
     in->is_float = wi.type == 3;
     if ((wi.channels != 1 && wi.channels != 2) ||
@@ -172,6 +177,24 @@ bool load_input(const char *path, const Options &opt, Input *in)
     else if (in->ec.mode == 3) in->ec.mode = 1;
     in->ec.samprate = wi.rate;
     in->frame_in = 1152 * wi.channels * (wi.bits / 8);
+    return true;
+}
+
+// cvt_to_pcm (pcmhpm.c:454-484): big-endian samples to host byte order
+void to_host_order(const WavInfo &wi, unsigned char *p, size_t nbytes)
+{
+    if (!wi.bigendian || wi.bits <= 8) return;
+    const size_t bs = (size_t) wi.bits / 8, ns = nbytes / bs;
+    for (size_t i = 0; i < ns; i++) std::reverse(p + i * bs, p + (i + 1) * bs);
+}
+
+// a whole input in memory (regular files of the batched routes)
+bool load_input(const char *path, const Options &opt, Input *in)
+{
+    FILE *f = nullptr;
+    uint64_t indatasize = 0;
+    if (!open_input(path, opt, in, &f, &indatasize)) { if (f && f != stdin) fclose(f); return false; }
+    const WavInfo &wi = in->wi;
     std::vector<unsigned char> chunk(1 << 20);
     while (in->data.size() < indatasize) {
         size_t want = chunk.size();
@@ -180,10 +203,7 @@ bool load_input(const char *path, const Options &opt, Input *in)
         in->data.insert(in->data.end(), chunk.begin(), chunk.begin() + got);
         if (got < want) break;
     }
-    if (wi.bigendian && wi.bits > 8) {      // cvt_to_pcm (pcmhpm.c:454-484): samples to host byte order
-        const size_t bs = (size_t) wi.bits / 8, ns = in->data.size() / bs;
-        for (size_t i = 0; i < ns; i++) std::reverse(in->data.begin() + i * bs, in->data.begin() + (i + 1) * bs);
-    }
+    to_host_order(wi, in->data.data(), in->data.size());
     in->audio_bytes = in->data.size();
     if (f != stdin) fclose(f);
     return true;
@@ -223,62 +243,142 @@ int encode_loaded(std::vector<Input> &in, const std::vector<const char *> &files
 
 bool mpeg_rate(int r) { return r == 32000 || r == 44100 || r == 48000 || r == 16000 || r == 22050 || r == 24000; }
 
-int encode_one_file(const char *fin, const char *fout, const Options &opt)
+// tomp3.cpp:1169-1196 (-EC)
+void print_ec(const HX_E_CONTROL *ec)
+{
+    fprintf(stderr, "\n-------------------------------------------------------------------------------");
+    fprintf(stderr, "\nec->layer =         %d\t\t\tec->mode =          %d", ec->layer, ec->mode);
+    fprintf(stderr, "\nec->bitrate =       %d\t\t\tec->samprate =      %d", ec->bitrate, ec->samprate);
+    fprintf(stderr, "\nec->nsbstereo =     %d\t\t\tec->freq_limit =    %d", ec->nsbstereo, ec->freq_limit);
+    fprintf(stderr, "\nec->filter_select = %d\t\t\tec->nsb_limit =     %d", ec->filter_select, ec->nsb_limit);
+    fprintf(stderr, "\nec->cr_bit =        %d\t\t\tec->original =      %d", ec->cr_bit, ec->original);
+    fprintf(stderr, "\nec->hf_flag =       %d\t\t\tec->vbr_flag =      %d", ec->hf_flag, ec->vbr_flag);
+    fprintf(stderr, "\nec->vbr_mnr =       %d\t\t\tec->vbr_br_limit =  %d", ec->vbr_mnr, ec->vbr_br_limit);
+    fprintf(stderr, "\nec->sparse_scale =  %d\t\t\tec->chan_add_f0 =   %d", ec->sparse_scale, ec->chan_add_f0);
+    fprintf(stderr, "\nec->vbr_delta_mnr = %d\t\t\tec->chan_add_f1 =   %d", ec->vbr_delta_mnr, ec->chan_add_f1);
+    fprintf(stderr, "\nec->quick =         %d\t\t\tec->cpu_select =    %d", ec->quick, ec->cpu_select);
+    fprintf(stderr, "\nec->test1 =         %d\t\t\tec->short_block_threshold = %d", ec->test1, ec->short_block_threshold);
+    fprintf(stderr, "\n-------------------------------------------------------------------------------");
+}
+
+// regular files up to this size take the batched route (whole file in memory); larger ones and pipes stream
+const uint64_t kBatchRouteMaxBytes = 1ull << 30;
+
+bool regular_file_size(const char *path, uint64_t *size)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    const bool ok = fseek(f, 0, SEEK_END) == 0;
+    const long n = ok ? ftell(f) : -1;
+    fclose(f);
+    if (n < 0) return false;
+    *size = (uint64_t) n;
+    return true;
+}
+
+// The reference's loop (tomp3.cpp:897-1050) with its bounded buffers: the input is read in pieces into a
+// sliding window, every call's bytes are written as they arrive, the tag is completed by seeking back at the
+// end.  Memory does not grow with the length of the input, so an unbounded pipe works.
+int encode_streaming(const char *fin, const char *fout, const Options &opt)
 {
     Input in;
-    if (!load_input(fin, opt, &in)) return 1;
-    if (!opt.mpeg_select && mpeg_rate(in.wi.rate) && strcmp(fout, "-")) {
-        // No rate conversion and a seekable output: the file goes through the batched API as a batch of one
-        // (96 frames per call instead of one), which writes exactly what the frame-by-frame loop below writes.
-        std::vector<Input> one(1);
-        one[0] = std::move(in);
-        return encode_loaded(one, {fin, fout}, opt);
-    }
+    FILE *fi = nullptr;
+    uint64_t indatasize = 0;
+    if (!open_input(fin, opt, &in, &fi, &indatasize)) { if (fi && fi != stdin) fclose(fi); return 1; }
+    int rc = 1;
     hx_enc *enc = hx_enc_create(0);
-    // bytes a call needs in the buffer (more than it consumes); with a sample-rate conversion a call consumes a varying amount
-    const int init_bytes = enc ? hx_enc_MP3_audio_encode_init(enc, &in.ec, in.wi.bits, in.is_float, opt.mpeg_select, in.mono_convert) : 0;
-    if (!init_bytes) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
-    in.pad(init_bytes);
-    FILE *out = strcmp(fout, "-") ? fopen(fout, "w+b") : stdout;
-    if (!out) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE\n"); return 1; }
-    char info[128];
-    hx_enc_info_string(enc, info);
-    fprintf(stderr, "\n %s\n", info);
-    hx_enc_info_ec(enc, &in.ec_used);       // the settings actually in use
-    hx_enc_info_head(enc, &in.head);
-    Tagger tg;
-    tg.begin(in, opt.xing_flag);
-    uint64_t out_bytes = tg.head_bytes;
-    if (tg.head_bytes && fwrite(tg.tag.data(), 1, tg.head_bytes, out) != (size_t) tg.head_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); return 1; }
+    FILE *out = nullptr;
+    do {
+        // bytes a call needs in the buffer (more than it consumes); with a sample-rate conversion a call consumes a varying amount
+        const int init_bytes = enc ? hx_enc_MP3_audio_encode_init(enc, &in.ec, in.wi.bits, in.is_float, opt.mpeg_select, in.mono_convert) : 0;
+        if (!init_bytes) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); break; }
+        out = strcmp(fout, "-") ? fopen(fout, "w+b") : stdout;
+        if (!out) { fprintf(stderr, "\n CANNOT CREATE OUTPUT FILE\n"); break; }
+        char info[128];
+        hx_enc_info_string(enc, info);
+        fprintf(stderr, "\n %s\n", info);
+        hx_enc_info_ec(enc, &in.ec_used);       // the settings actually in use
+        hx_enc_info_head(enc, &in.head);
+        if (opt.ec_display) print_ec(&in.ec_used);
+        Tagger tg;
+        tg.begin(in, opt.xing_flag);
+        uint64_t out_bytes = tg.head_bytes;
+        if (tg.head_bytes && fwrite(tg.tag.data(), 1, tg.head_bytes, out) != (size_t) tg.head_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); break; }
 
-    std::vector<unsigned char> bs(128 * 1024), zero((size_t) 4 * init_bytes + (1 << 17), 0);
-    unsigned frames_expected = 0;
-    auto emit = [&](const HX_IN_OUT &x) {
-        if (x.out_bytes && fwrite(bs.data(), 1, x.out_bytes, out) != (size_t) x.out_bytes) { fprintf(stderr, "\n FILE WRITE ERROR\n"); exit(1); }
-        tg.bytes(bs.data(), x.out_bytes);
-        out_bytes += x.out_bytes;
-    };
-    for (size_t off = 0; off + init_bytes <= in.size; ) {                           // tomp3.cpp:904-1003
-        const HX_IN_OUT x = hx_enc_MP3_audio_encode(enc, in.data.data() + off, bs.data());
-        emit(x);
-        off += x.in_bytes;
-        frames_expected++;
-        const HX_INT_PAIR fb = hx_enc_get_frames_bytes(enc);
-        tg.after_call((unsigned) fb.a, (unsigned) fb.b);
-    }
-    if (in.ec_used.samprate < 32000) frames_expected *= 2;                          // MPEG-2: two frames per call (tomp3.cpp:1022)
-    while (hx_enc_get_frames(enc) < frames_expected)                                // drain, tomp3.cpp:1020-1036
-        emit(hx_enc_MP3_audio_encode(enc, zero.data(), bs.data()));
-    const unsigned frames = hx_enc_get_frames(enc);
-    if (opt.xing_flag) {
-        tg.finish(in, frames, out_bytes);
-        if (out == stdout || fseek(out, 0, SEEK_SET) != 0) fprintf(stderr, "\n OUTPUT IS NOT SEEKABLE: TAG FRAME LEFT WITHOUT TOTALS");
-        else fwrite(tg.tag.data(), 1, tg.head_bytes, out);
-    }
-    fprintf(stderr, "\n %u frames, %llu bytes, %.2f kbps\n", frames, (unsigned long long) out_bytes, hx_enc_get_bitrate_float(enc));
-    if (out != stdout) fclose(out);
+        // window over (audio ++ 4 x init_bytes zero bytes): a call is made while at least init_bytes are
+        // left (tomp3.cpp:904-941); the converter may stage more than it consumes, hence the slack
+        const size_t slack = 1 << 17, piece = 1 << 20;
+        std::vector<unsigned char> win(piece + (size_t) init_bytes + slack, 0), bs(128 * 1024), zero((size_t) 4 * init_bytes + slack, 0);
+        size_t lo = 0, hi = 0;                  // valid bytes of the window: [lo, hi)
+        uint64_t audio = 0, zeros_left = 4ull * (uint64_t) init_bytes;
+        bool eof = false, werr = false;
+        unsigned frames_expected = 0;
+        auto emit = [&](const HX_IN_OUT &x) {
+            if (x.out_bytes && fwrite(bs.data(), 1, x.out_bytes, out) != (size_t) x.out_bytes) werr = true;
+            tg.bytes(bs.data(), x.out_bytes);
+            out_bytes += x.out_bytes;
+        };
+        for (;;) {
+            if (hi - lo < (size_t) init_bytes && !(eof && zeros_left == 0)) {      // refill
+                memmove(win.data(), win.data() + lo, hi - lo);
+                hi -= lo; lo = 0;
+                while (hi < piece && !(eof && zeros_left == 0)) {
+                    if (!eof) {
+                        size_t want = piece - hi;
+                        if ((uint64_t) want > indatasize - audio) want = (size_t) (indatasize - audio);
+                        const size_t got = want ? fread(win.data() + hi, 1, want, fi) : 0;
+                        to_host_order(in.wi, win.data() + hi, got);     // (pieces are whole samples: 1 MiB is a multiple of 1..4-byte samples; a torn last sample is padding anyway)
+                        hi += got; audio += got;
+                        if (got < want || audio >= indatasize) eof = true;
+                    } else {
+                        const size_t z = (size_t) std::min<uint64_t>(zeros_left, piece - hi);
+                        memset(win.data() + hi, 0, z);
+                        hi += z; zeros_left -= z;
+                    }
+                }
+                memset(win.data() + hi, 0, win.size() - hi);
+            }
+            if (hi - lo < (size_t) init_bytes) break;
+            const HX_IN_OUT x = hx_enc_MP3_audio_encode(enc, win.data() + lo, bs.data());
+            emit(x);
+            lo += (size_t) x.in_bytes;
+            frames_expected++;
+            const HX_INT_PAIR fb = hx_enc_get_frames_bytes(enc);
+            tg.after_call((unsigned) fb.a, (unsigned) fb.b);
+            if (werr) break;
+        }
+        in.audio_bytes = audio;
+        if (in.ec_used.samprate < 32000) frames_expected *= 2;                          // MPEG-2: two frames per call (tomp3.cpp:1022)
+        while (!werr && hx_enc_get_frames(enc) < frames_expected)                       // drain, tomp3.cpp:1020-1036
+            emit(hx_enc_MP3_audio_encode(enc, zero.data(), bs.data()));
+        if (werr) { fprintf(stderr, "\n FILE WRITE ERROR\n"); break; }
+        const unsigned frames = hx_enc_get_frames(enc);
+        if (opt.xing_flag) {
+            tg.finish(in, frames, out_bytes);
+            if (out == stdout || fseek(out, 0, SEEK_SET) != 0) fprintf(stderr, "\n OUTPUT IS NOT SEEKABLE: TAG FRAME LEFT WITHOUT TOTALS");
+            else fwrite(tg.tag.data(), 1, tg.head_bytes, out);
+        }
+        fprintf(stderr, "\n %u frames, %llu bytes, %.2f kbps\n", frames, (unsigned long long) out_bytes, hx_enc_get_bitrate_float(enc));
+        rc = frames == 0 ? 1 : 0;
+    } while (0);
+    if (out && out != stdout) fclose(out);
+    if (fi && fi != stdin) fclose(fi);
     hx_enc_destroy(enc);
-    return frames == 0 ? 1 : 0;
+    return rc;
+}
+
+int encode_one_file(const char *fin, const char *fout, const Options &opt)
+{
+    // A regular file of bounded size at an MPEG rate with a seekable output goes through the batched API as a
+    // batch of one (96 frames per call instead of one), which writes exactly what the frame-by-frame loop
+    // writes.  Pipes, very large files and inputs that need a rate conversion stream frame by frame.
+    uint64_t fsize = 0;
+    if (!opt.mpeg_select && strcmp(fin, "-") && strcmp(fout, "-") && regular_file_size(fin, &fsize) && fsize <= kBatchRouteMaxBytes) {
+        std::vector<Input> one(1);
+        if (!load_input(fin, opt, &one[0])) return 1;
+        if (mpeg_rate(one[0].wi.rate)) return encode_loaded(one, {fin, fout}, opt);
+    }
+    return encode_streaming(fin, fout, opt);
 }
 
 // samples of one input frame as fp32 at int16 scale, the way Csrc::sr_convert / src_filter_to_mono_case0
@@ -341,9 +441,12 @@ int encode_loaded(std::vector<Input> &in, const std::vector<const char *> &files
     }
     const int CH = 96;                                  // frames per batched call
     const size_t total = max_calls + 32;                // room for the drain frames (a reservoir never spans that many)
-    hx_batch *b = hx_batch_create(0, S, ctl.data(), 0, CH);
+    // the files spread over the node's GPUs in contiguous blocks (-Gn limits the count), one host thread per device
+    hx_multi *b = hx_multi_create(opt.ngpus, nullptr, S, ctl.data(), 0, CH);
     if (!b) { fprintf(stderr, "\n ENCODER INIT FAIL: %s\n", hx_last_error()); return 1; }
-    const long long stride = hx_batch_out_stride(b, CH);
+    if (S > 1) fprintf(stderr, "\n %d files on %d GPU(s)", S, hx_multi_ndevices(b));
+    if (opt.ec_display) print_ec(&in[0].ec_used);
+    const long long stride = hx_multi_out_stride(b, CH);
     std::vector<float> pcm((size_t) S * CH * 1152 * nch), tmp(2304);
     const std::vector<unsigned char> zero_frame(2304 * 4, 0);
     std::vector<unsigned char> out((size_t) S * stride);
@@ -361,8 +464,9 @@ int encode_loaded(std::vector<Input> &in, const std::vector<const char *> &files
                 memcpy(&pcm[((size_t) i * CH + k) * 1152 * nch], tmp.data(), sizeof(float) * 1152 * nch);
             }
         }
-        if (hx_batch_encode_f32_host_stats(b, pcm.data(), CH, out.data(), stride, nb.data(), stats.data()) != 0) {
+        if (hx_multi_encode_f32_host_stats(b, pcm.data(), CH, out.data(), stride, nb.data(), stats.data()) != 0) {
             fprintf(stderr, "\n ENCODE FAIL: %s\n", hx_last_error());
+            hx_multi_destroy(b);
             return 1;
         }
         for (int i = 0; i < S; i++) {
@@ -370,8 +474,8 @@ int encode_loaded(std::vector<Input> &in, const std::vector<const char *> &files
             for (int k = 0; k < CH; k++) { fr[i].push_back((unsigned) stats[((size_t) i * CH + k) * 2]); by[i].push_back((unsigned) stats[((size_t) i * CH + k) * 2 + 1]); }
         }
     }
-    if (hx_batch_status(b) != 0) fprintf(stderr, "\n WARNING: kernel status %d\n", hx_batch_status(b));
-    hx_batch_destroy(b);
+    if (hx_multi_status(b) != 0) fprintf(stderr, "\n WARNING: kernel status %d\n", hx_multi_status(b));
+    hx_multi_destroy(b);
     // per file: what the single-file loop would have written
     int rc = 0;
     for (int i = 0; i < S; i++) {
@@ -415,6 +519,9 @@ int main(int argc, char **argv)
         const char c = (char) (a[1] | 0x20), c2 = (char) (a[2] | 0x20);
         switch (c) {
         case 'h': if (c2 == 'f') ec.hf_flag = 1 | atoi(a + 3); else { usage(); return 0; } break;
+        case 'e': if (c2 == 'c') opt.ec_display = 1; break;            // -EC: print the settings in use (tomp3.cpp:412-416)
+        case 'g': opt.ngpus = atoi(a + 2); break;                      // -Gn: GPUs for -batch (default: all)
+        case 'd': case 'p': case 'z': break;                            // -D progress display off, -P / -Z reserved (tomp3.cpp:438-441,470-472,508-511): nothing to do here
         case 'q': ec.quick = atoi(a + 2); break;
         case 'u': ec.cpu_select = atoi(a + 2); break;
         case 'x': opt.xing_flag = atoi(a + 2); if (opt.xing_flag == 2) opt.xing_flag = 3; break;
@@ -431,7 +538,7 @@ int main(int argc, char **argv)
         case 'v': ec.vbr_flag = 1; ec.vbr_mnr = atoi(a + 2); break;
         case 'l': ec.vbr_br_limit = atoi(a + 2); break;
         case 'a': opt.mpeg_select = atoi(a + 2); if (opt.mpeg_select < 0) opt.mpeg_select = 0; break;
-        default: break;             // -D -EC -P -Z -W: display / reserved switches, no effect on the stream
+        default: break;             // -W and unknown switches: ignored like the reference does
         }
     }
     opt.ec.vbr_flag = opt.ec.bitrate < 0 ? 1 : 0;

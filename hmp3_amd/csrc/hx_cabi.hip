@@ -30,7 +30,7 @@ struct AllocArgs {
     unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status; unsigned long long *prof;
     unsigned char *packet; long long packet_stride; int *packet_bytes; int *frame_stats; int *done_counter;
 };
-__global__ void k_gate(const int *done_counter, int target);
+__global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
 
@@ -43,6 +43,10 @@ static void set_err(const char *fmt, const char *a = "")
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("HIP error: %s", hipGetErrorString(e_)); return -1; } } while (0)
 #define HIPCHKN(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("HIP error: %s", hipGetErrorString(e_)); return nullptr; } } while (0)
+// every kernel launch is checked where it is made: a bad configuration or a lost device is reported
+// with the kernel's name instead of surfacing at some later call
+#define LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); \
+        hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err("launch of " #kernel " failed: %s", hipGetErrorString(e_)); return -1; } } while (0)
 
 struct hx_batch {
     int device = 0, S = 0, maxF = 0, ncls = 0;
@@ -86,8 +90,9 @@ struct hx_batch {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr, s_host = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr}, ev_hfront[2] = {nullptr, nullptr};
     long long nhost = 0;
-    int *d_done = nullptr;              // streams retired by all k_alloc launches of this batch
+    int *d_done = nullptr;              // [0] streams retired by all k_alloc launches of this batch (wraps), [1] gate time-outs
     long long alloc_launches = 0;
+    unsigned long long cfg_hash = 0;    // fingerprint of the resolved configuration classes (checkpoint blobs carry their stream's)
     int gate_percent = 90;              // a submit's front end starts once this share of the previous call's streams is done
 };
 
@@ -136,6 +141,13 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err("no HIP device available: the encoder has no CPU fallback"); return nullptr; }
     if (device < 0 || device >= ndev) { set_err("device index out of range"); return nullptr; }
+    {   // written for gfx950 (MI355X) only: the code object holds no other target
+        hipDeviceProp_t prop;
+        HIPCHKN(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_err("device is %s: this library runs on gfx950 (MI355X) only", prop.gcnArchName); return nullptr; }
+    }
+    // the launch bookkeeping (streams x granules x 9 energies per channel) is 32-bit
+    if ((long long) nstreams * max_frames > 32LL * 1024 * 1024) { set_err("nstreams * max_frames exceeds 32 Mi frames per call: split the batch"); return nullptr; }
     HIPCHKN(hipSetDevice(device));
     hx_batch *b = new hx_batch;
     b->device = device; b->S = nstreams; b->maxF = max_frames;
@@ -181,8 +193,8 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_btprev, S);
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
-    ALLOC(b->d_done, sizeof(int));
-    HIPCHKN(hipMemset(b->d_done, 0, sizeof(int)));
+    ALLOC(b->d_done, 2 * sizeof(int));
+    HIPCHKN(hipMemset(b->d_done, 0, 2 * sizeof(int)));
     if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 1152 * b->nchan);
     HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(b->d_gt, &gt, sizeof(gt), hipMemcpyHostToDevice));
@@ -198,14 +210,38 @@ extern "C" int hx_batch_nstreams(const hx_batch *b) { return b ? b->S : 0; }
 // Checkpoint of one stream: its HxStream record followed by the three carried subband granules of each
 // channel.  With it a stream continues in another slot, another batch of the same configuration, another GPU or
 // after a restart exactly where it stopped (the reference's equivalent is a copy of the CMp3Enc object).
-extern "C" long long hx_batch_stream_state_bytes(const hx_batch *b) { (void) b; return (long long) (sizeof(HxStream) + 2 * 3 * 576 * sizeof(float)); }
+// The blob starts with a header {magic, format version, sizeof(HxStream), fingerprint of the stream's resolved
+// configuration}: a blob from another library build (other state layout) or saved under another control is
+// refused instead of silently yielding a corrupt bitstream.
+struct HxStateHeader { unsigned magic, version, state_bytes, pad; unsigned long long cfg; };
+#define HX_STATE_MAGIC 0x53335848u      // "HX3S"
+#define HX_STATE_VERSION 2u
+static unsigned long long cfg_fingerprint(const HxParams &p)
+{
+    unsigned long long h = 1469598103934665603ull;      // FNV-1a over the echoed control and the derived frame constants
+    auto mix = [&](const void *d, size_t n) { const unsigned char *c = (const unsigned char *) d; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } };
+    mix(&p.ec, sizeof(p.ec));
+    const int v[] = {p.totbitrate, p.samprate, p.h_mode, p.h_id, p.nchan, p.nsb_limit, p.band_limit, p.framebytes, p.main_framebytes, p.side_bytes,
+                     p.ms_flag, p.hf_flag, p.vbr_flag, p.initialMNR, p.short_block_threshold};
+    mix(v, sizeof(v));
+    return h;
+}
+extern "C" long long hx_batch_stream_state_bytes(const hx_batch *b) { (void) b; return (long long) (sizeof(HxStateHeader) + sizeof(HxStream) + 2 * 3 * 576 * sizeof(float)); }
 
 static int stream_state_copy(hx_batch *b, int i, void *host, bool save)
 {
     if (!b || i < 0 || i >= b->S || !host) { set_err("bad arguments"); return -1; }
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
-    char *h = (char *) host;
+    HxStateHeader hd = {HX_STATE_MAGIC, HX_STATE_VERSION, (unsigned) sizeof(HxStream), 0, cfg_fingerprint(b->params[b->cls_of[i]])};
+    if (save) memcpy(host, &hd, sizeof(hd));
+    else {
+        HxStateHeader in;
+        memcpy(&in, host, sizeof(in));
+        if (in.magic != HX_STATE_MAGIC || in.version != HX_STATE_VERSION || in.state_bytes != hd.state_bytes) { set_err("not a stream-state blob of this library build"); return -1; }
+        if (in.cfg != hd.cfg) { set_err("the stream state was saved under a different configuration than slot's"); return -1; }
+    }
+    char *h = (char *) host + sizeof(HxStateHeader);
     const size_t per = (size_t) (2 * b->maxF + 3) * 576;        // floats per (stream, channel) in the subband buffer
     if (save) {
         HIPCHK(hipMemcpy(h, b->d_st + i, sizeof(HxStream), hipMemcpyDeviceToHost));
@@ -244,6 +280,7 @@ extern "C" int hx_batch_reset_stream(hx_batch *b, int i)
 
 extern "C" long long hx_batch_out_stride(const hx_batch *b, int nframes)
 {
+    if (!b) return 0;
     // nframes new frames plus the images of the frames still pending from earlier calls (their
     // free space is at most the 511-byte reservoir, so a handful of frames; 4 KB covers them)
     int maxframe = 0;
@@ -297,15 +334,23 @@ static int pipe_init(hx_batch *b)
     return 0;
 }
 
+// Argument checks of every encode entry point, made before anything is allocated, copied or launched.
+static int check_call(const hx_batch *b, const void *pcm, int nframes, const void *out, long long out_stride, const void *out_bytes)
+{
+    if (!b) { set_err("null batch"); return -1; }
+    if (nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range (1 .. max_frames of hx_batch_create)"); return -1; }
+    if (!pcm || !out || !out_bytes) { set_err("null buffer"); return -1; }
+    if (out_stride < hx_batch_out_stride(b, nframes)) { set_err("out_stride is smaller than hx_batch_out_stride(b, nframes)"); return -1; }
+    return 0;
+}
+
 // one pass of the pipeline over the batch; the input is int16 (d_pcm) or fp32 at int16 scale (d_pcm32).
 // pipelined = 0: every kernel on the caller's stream.  pipelined = 1 (hx_batch_submit_*): front end
 // and k_alloc on the batch's own two streams, ordered by events (see hx_batch).
 static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, int nframes, unsigned char *d_out,
                        long long out_stride, int *d_out_bytes, void *stream, int pipelined = 0)
 {
-    if (!b || nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range"); return -1; }
-    if (!d_out || !d_out_bytes || (!d_pcm && !d_pcm32)) { set_err("null buffer"); return -1; }
-    if (out_stride < hx_batch_out_stride(b, nframes)) { set_err("out_stride is smaller than hx_batch_out_stride(b, nframes)"); return -1; }
+    if (check_call(b, d_pcm ? (const void *) d_pcm : (const void *) d_pcm32, nframes, d_out, out_stride, d_out_bytes) != 0) return -1;
     hipStream_t q = (hipStream_t) stream, qa = q;
     HIPCHK(hipSetDevice(b->device));
     int set = 0;
@@ -317,8 +362,9 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_alloc[set], 0));     // k_alloc of submit n-2 is done with this set
         q = b->s_front; qa = b->s_alloc;
         if (b->alloc_launches > 0 && b->gate_percent > 0) {        // start in the previous allocator kernel's tail, not at its start
-            const long long target = (b->alloc_launches - 1) * b->S + (long long) b->S * b->gate_percent / 100;
-            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, b->d_done, (int) target);
+            const unsigned base = (unsigned) ((unsigned long long) (b->alloc_launches - 1) * (unsigned long long) b->S);   // wraps with the counter
+            const unsigned need = (unsigned) ((long long) b->S * b->gate_percent / 100);
+            LAUNCH(k_gate, dim3(1), dim3(64), q, (const unsigned *) b->d_done, base, need, b->d_done + 1);
         }
     } else if (b->inflight) {                                       // a plain call behind submits: order it after them
         const int last = (int) ((b->nsubmit - 1) & 1);
@@ -336,19 +382,18 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     dim3 g1(S, (NG + K1_GPB - 1) / K1_GPB);
     const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
     const float *pcmf = b->any_dc ? b->d_pcmf : d_pcm32;       // fp32 samples the polyphase reads, or null for int16
-    if (b->any_dc) hipLaunchKernelGGL(k_dcfilter, dim3((b->nchan * S + 63) / 64), dim3(64), 0, q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S, b->nchan);
-    hipLaunchKernelGGL(k_polyphase, g1, dim3(512), 0, q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan);
-    int tot = S * 2 * NG * 9;
-    hipLaunchKernelGGL(k_attack_eng, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot, b->lsf);
+    if (b->any_dc) LAUNCH(k_dcfilter, dim3((b->nchan * S + 63) / 64), dim3(64), q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S, b->nchan);
+    LAUNCH(k_polyphase, g1, dim3(512), q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan);
+    int tot = (int) ((long long) S * 2 * NG * 9);       // < 2^31: hx_batch_create bounds nstreams * max_frames
+    LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot, b->lsf);
     tot = S * NG;
-    hipLaunchKernelGGL(k_attack_flg, dim3((tot + 255) / 256), dim3(256), 0, q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
-                       b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
-    hipLaunchKernelGGL(k_blocktype, dim3((S + 63) / 64), dim3(64), 0, q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
-    long long units = (long long) S * NG * 2;
-    hipLaunchKernelGGL(k_spec, dim3((unsigned) (S * NG)), dim3(64), 0, q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
-                       x_etab, x_thr, x_msbase, NG, SG);
+    LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
+           b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
+    LAUNCH(k_blocktype, dim3((S + 63) / 64), dim3(64), q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
+    LAUNCH(k_spec, dim3((unsigned) ((long long) S * NG)), dim3(64), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
+           x_etab, x_thr, x_msbase, NG, SG);
     // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
-    hipLaunchKernelGGL(k_carry, dim3(S * 2), dim3(256), 0, q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
+    LAUNCH(k_carry, dim3(S * 2), dim3(256), q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
     if (pipelined) {
         HIPCHK(hipEventRecord(b->ev_front[set], q));
         HIPCHK(hipStreamWaitEvent(qa, b->ev_front[set], 0));
@@ -364,8 +409,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, qa));
-    if (b->lsf) hipLaunchKernelGGL(k_alloc_lsf, dim3(S), dim3(128), 0, qa, a);
-    else hipLaunchKernelGGL(k_alloc, dim3(S), dim3(128), 0, qa, a);
+    if (b->lsf) LAUNCH(k_alloc_lsf, dim3(S), dim3(128), qa, a);
+    else LAUNCH(k_alloc, dim3(S), dim3(128), qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
     while (b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events
@@ -447,7 +492,7 @@ extern "C" void hx_pinned_free(void *p) { if (p) hipHostFree(p); }
 
 static int submit_host(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
 {
-    if (!b) return -1;
+    if (check_call(b, pcm, nframes, out, out_stride, out_bytes) != 0) return -1;
     HIPCHK(hipSetDevice(b->device));
     const long long pbytes = (long long) b->S * nframes * 1152 * b->nchan * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
     if (!b->s_h2d) {
@@ -530,7 +575,7 @@ extern "C" float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls)
 
 static int encode_host(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
 {
-    if (!b) return -1;
+    if (check_call(b, pcm, nframes, out, out_stride, out_bytes) != 0) return -1;
     HIPCHK(hipSetDevice(b->device));
     long long pbytes = (long long) b->S * nframes * 1152 * b->nchan * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
     if (pbytes > b->pcm_cap) { if (b->d_pcm) hipFree(b->d_pcm); HIPCHK(hipMalloc((void **) &b->d_pcm, pbytes)); b->pcm_cap = pbytes; }
@@ -555,7 +600,8 @@ extern "C" int hx_batch_encode_s16_host(hx_batch *b, const int16_t *pcm, int nfr
 extern "C" int hx_batch_encode_f32_host_stats(hx_batch *b, const float *pcm, int nframes, unsigned char *out,
                                               long long out_stride, int *out_bytes, int *stats)
 {
-    if (!b || !stats) return -1;
+    if (!stats) { set_err("null buffer"); return -1; }
+    if (check_call(b, pcm, nframes, out, out_stride, out_bytes) != 0) return -1;
     HIPCHK(hipSetDevice(b->device));
     int *d_stats = nullptr;
     const size_t n = sizeof(int) * (size_t) b->S * nframes * 2;
@@ -588,11 +634,24 @@ extern "C" int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nfram
 
 extern "C" int hx_batch_status(hx_batch *b)
 {
-    int v = -1;
+    int v = -1, gate[2] = {0, 0};
+    if (!b) return -1;
     hipSetDevice(b->device);
     hipDeviceSynchronize();
-    hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost);
+    if (hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(gate, b->d_done, sizeof(gate), hipMemcpyDeviceToHost) == hipSuccess && gate[1] > 0) v |= 8;
     return v;
+}
+
+// submits whose front end started late because its gate gave up waiting (see hx_batch_set_gate); synchronises
+extern "C" int hx_batch_gate_timeouts(hx_batch *b)
+{
+    int gate[2] = {0, 0};
+    if (!b) return -1;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    if (hipMemcpy(gate, b->d_done, sizeof(gate), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return gate[1];
 }
 
 extern "C" HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int i)
@@ -610,6 +669,7 @@ extern "C" HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int i)
 
 extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *dst, long long cap)
 {
+    if (!b || !name || !dst) return -1;
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     const long long S = b->S, NG = b->lastNG;
@@ -848,6 +908,17 @@ extern "C" HX_IN_OUT hx_enc_MP3_audio_encode(hx_enc *e, const unsigned char *pcm
     return x;
 }
 
+extern "C" void hx_enc_out_stats(hx_enc *e)
+{
+    int calls = 0;
+    if (e && e->b) {
+        hipSetDevice(e->b->device);
+        hipDeviceSynchronize();
+        hipMemcpy(&calls, (char *) e->b->d_st + offsetof(HxStream, call_count), sizeof(int), hipMemcpyDeviceToHost);
+    }
+    fprintf(stderr, "\n ba long  %6d %6d %6d %6d %6d %6d %6d %6d %6d", calls, 0, 0, 0, 0, 0, 0, 0, 0);
+}
+
 extern "C" unsigned hx_enc_get_frames(hx_enc *e) { return e->frames; }
 extern "C" HX_INT_PAIR hx_enc_get_frames_bytes(hx_enc *e) { HX_INT_PAIR r = {(int) e->frames, (int) e->bytes}; return r; }
 extern "C" float hx_enc_get_bitrate_float(hx_enc *e)
@@ -876,4 +947,107 @@ extern "C" void hx_enc_info_string(hx_enc *e, char *s)
         if (ec->vbr_delta_mnr) s += sprintf(s, "(%d)", ec->vbr_delta_mnr);
     }
     if (ec->hf_flag) { s += sprintf(s, "  hf"); if (ec->hf_flag & 2) s += sprintf(s, "2"); }
+}
+
+// ------------------------------------------------------------------------------------------
+// Several GPUs of one node behind one handle: the streams are split into contiguous
+// blocks, one hx_batch per device, and every call runs one host thread per device on its block of the
+// caller's buffers.  Streams are independent, so nothing is exchanged between the devices.
+#include <thread>
+struct hx_multi {
+    std::vector<hx_batch *> part;
+    std::vector<int> first, count, device;
+    int S = 0, nchan = 2;
+};
+
+extern "C" void hx_multi_destroy(hx_multi *m)
+{
+    if (!m) return;
+    for (hx_batch *b : m->part) hx_batch_destroy(b);
+    delete m;
+}
+
+extern "C" hx_multi *hx_multi_create(int ndev, const int *devices, int nstreams, const HX_E_CONTROL *ec, int shared_control, int max_frames)
+{
+    if (nstreams <= 0 || max_frames <= 0 || !ec) { set_err("bad arguments"); return nullptr; }
+    const int have = hx_device_count();
+    if (ndev <= 0) ndev = have;
+    if (ndev > nstreams) ndev = nstreams;
+    if (ndev <= 0) { set_err("no HIP device available: the encoder has no CPU fallback"); return nullptr; }
+    hx_multi *m = new hx_multi;
+    m->S = nstreams;
+    const int base = nstreams / ndev, rem = nstreams % ndev;       // block sizes differ by at most one (hmp3_amd/shard.py)
+    for (int k = 0; k < ndev; k++) {
+        const int first = k * base + (k < rem ? k : rem), count = base + (k < rem ? 1 : 0);
+        const int dev = devices ? devices[k] : k;
+        hx_batch *b = hx_batch_create(dev, count, shared_control ? ec : ec + first, shared_control, max_frames);
+        if (!b) { hx_multi_destroy(m); return nullptr; }            // hx_last_error is hx_batch_create's
+        m->part.push_back(b); m->first.push_back(first); m->count.push_back(count); m->device.push_back(dev);
+        if (k == 0) m->nchan = b->nchan;
+        else if (b->nchan != m->nchan || b->lsf != m->part[0]->lsf) { set_err("mono / stereo and MPEG-1 / MPEG-2 streams cannot share a batch"); hx_multi_destroy(m); return nullptr; }
+    }
+    return m;
+}
+
+extern "C" int hx_multi_ndevices(const hx_multi *m) { return m ? (int) m->part.size() : 0; }
+extern "C" int hx_multi_nstreams(const hx_multi *m) { return m ? m->S : 0; }
+extern "C" hx_batch *hx_multi_batch(hx_multi *m, int k) { return (m && k >= 0 && k < (int) m->part.size()) ? m->part[k] : nullptr; }
+extern "C" int hx_multi_shard(const hx_multi *m, int k, int *device, int *first, int *count)
+{
+    if (!m || k < 0 || k >= (int) m->part.size()) return -1;
+    if (device) *device = m->device[k];
+    if (first) *first = m->first[k];
+    if (count) *count = m->count[k];
+    return 0;
+}
+
+extern "C" long long hx_multi_out_stride(const hx_multi *m, int nframes)
+{
+    long long n = 0;
+    if (m) for (hx_batch *b : m->part) { const long long v = hx_batch_out_stride(b, nframes); if (v > n) n = v; }
+    return n;
+}
+
+// one thread per device; kind 0 = int16, 1 = fp32, 2 = fp32 with per-frame counters
+static int multi_call(hx_multi *m, int kind, const void *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes, int *stats)
+{
+    if (!m || !pcm || !out || !out_bytes || (kind == 2 && !stats)) { set_err("null buffer"); return -1; }
+    if (out_stride < hx_multi_out_stride(m, nframes)) { set_err("out_stride is smaller than hx_multi_out_stride(m, nframes)"); return -1; }
+    const size_t n = m->part.size(), esz = kind ? sizeof(float) : sizeof(int16_t);
+    std::vector<int> rc(n, 0);
+    std::vector<std::string> err(n);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < n; k++)
+        th.emplace_back([&, k]() {
+            const long long f = m->first[k];
+            const char *p = (const char *) pcm + (size_t) f * nframes * 1152 * m->nchan * esz;
+            unsigned char *o = out + f * out_stride;
+            if (kind == 0) rc[k] = hx_batch_encode_s16_host(m->part[k], (const int16_t *) p, nframes, o, out_stride, out_bytes + f);
+            else if (kind == 1) rc[k] = hx_batch_encode_f32_host(m->part[k], (const float *) p, nframes, o, out_stride, out_bytes + f);
+            else rc[k] = hx_batch_encode_f32_host_stats(m->part[k], (const float *) p, nframes, o, out_stride, out_bytes + f, stats + f * nframes * 2);
+            if (rc[k]) err[k] = hx_last_error();        // the message is thread-local: hand it to the caller's thread
+        });
+    for (std::thread &t : th) t.join();
+    for (size_t k = 0; k < n; k++) if (rc[k]) { set_err("%s", err[k].c_str()); return rc[k]; }
+    return 0;
+}
+
+extern "C" int hx_multi_encode_s16_host(hx_multi *m, const int16_t *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
+{
+    return multi_call(m, 0, pcm, nframes, out, out_stride, out_bytes, nullptr);
+}
+extern "C" int hx_multi_encode_f32_host(hx_multi *m, const float *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
+{
+    return multi_call(m, 1, pcm, nframes, out, out_stride, out_bytes, nullptr);
+}
+extern "C" int hx_multi_encode_f32_host_stats(hx_multi *m, const float *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes, int *stats)
+{
+    return multi_call(m, 2, pcm, nframes, out, out_stride, out_bytes, stats);
+}
+extern "C" int hx_multi_status(hx_multi *m)
+{
+    int v = 0;
+    if (!m) return -1;
+    for (hx_batch *b : m->part) v |= hx_batch_status(b);
+    return v;
 }

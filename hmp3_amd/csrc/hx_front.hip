@@ -687,16 +687,17 @@ __global__ void k_dcfilter(const int16_t *__restrict__ pcm, const float *__restr
 }
 
 // Gate of a pipelined submit (hx_batch_submit_*): holds the stream it is launched on until the
-// allocator kernel of the previous call has retired `target` streams in total, so that the front-end
-// kernels behind it start in that kernel's tail instead of competing with its start.  Gives up after
-// ~50 ms (s_memtime ticks at 100 MHz): late is harmless, a hang is not.
-__global__ void k_gate(const int *done_counter, int target)
+// allocator kernel of the previous call has retired `need` of its streams, so that the front-end
+// kernels behind it start in that kernel's tail instead of competing with its start.  The counter
+// runs over all launches of the batch and may wrap: `base` is its value when the previous launch
+// began, and the distance is compared as unsigned.  Gives up after ~50 ms (late is harmless, a hang
+// is not) and counts that in *timeouts, so the caller can see that the overlap degraded.
+__global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts)
 {
     if (threadIdx.x != 0) return;
-    const long long t0 = clock64();
-    while (__hip_atomic_load(done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    const long long t0 = wall_clock64();        // 100 MHz
+    while (__hip_atomic_load(done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base < need) {
         __builtin_amdgcn_s_sleep(127);
-        if (clock64() - t0 > 5000000LL) break;
+        if (wall_clock64() - t0 > 5000000LL) { atomicAdd(timeouts, 1); break; }
     }
 }
-

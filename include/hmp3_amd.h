@@ -12,8 +12,9 @@
  * x F frames per call on one GPU, which is where the throughput comes from.  All buffers are
  * plain pointers; "device" variants take HIP device pointers and a hipStream_t (as void*).
  *
- * Everything runs on the GPU: there is no CPU fallback.  If no MI355X-class device is usable
- * the create calls return NULL / init returns 0 and hx_last_error() says why.
+ * Everything runs on the GPU: there is no CPU fallback.  hx_batch_create / the hx_enc init calls
+ * check that the device is a gfx950 (MI355X); if none is usable they return NULL / 0 and
+ * hx_last_error() says why.  Every kernel launch is checked where it is made.
  */
 #ifndef HMP3_AMD_H
 #define HMP3_AMD_H
@@ -78,6 +79,9 @@ void hx_enc_info_head(hx_enc *e, HX_MPEG_HEAD *head);       /* mp3enc.cpp:3498 *
 HX_IN_OUT hx_enc_L3_audio_encode_Packet(hx_enc *e, const float *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 HX_IN_OUT hx_enc_MP3_audio_encode_Packet(hx_enc *e, const unsigned char *pcm, unsigned char *bs_out, unsigned char *packet, int nbytes_out[2]);
 void hx_enc_info_string(hx_enc *e, char *s);                /* mp3enc.cpp:3505, <= 80 chars */
+/* CMp3Enc::out_stats (mp3enc.cpp:3522, "test routine"): the allocator's counters to stderr - the long-block
+   allocator's call count; the reference's remaining columns are uninitialised diagnostics and print as 0 */
+void hx_enc_out_stats(hx_enc *e);
 
 /* ---- sample-format / sample-rate converter (host side) ----
    What CMp3Enc::MP3_audio_encode runs in front of every frame: Csrc (pub/srcc.h:87-97).  hx_enc_MP3_audio_encode
@@ -100,9 +104,11 @@ int hx_batch_nstreams(const hx_batch *b);
 /* start a new stream in slot i with the slot's configuration (the state CMp3Enc::L3_audio_encode_init leaves,
    mp3enc.cpp:278-287, 788-837); waits for work in flight, leaves the other streams alone */
 int hx_batch_reset_stream(hx_batch *b, int i);
-/* checkpoint / resume of one stream (encoder state + subband carry, hx_batch_stream_state_bytes bytes): what is
-   saved from slot i continues, after hx_batch_set_stream_state, in any slot of any batch created with the same
-   control for that slot (any size, any max_frames) - another GPU or a later process included */
+/* checkpoint / resume of one stream (header + encoder state + subband carry, hx_batch_stream_state_bytes bytes):
+   what is saved from slot i continues, after hx_batch_set_stream_state, in any slot of any batch created with
+   the same control for that slot (any size, any max_frames) - another GPU or a later process included.  src
+   must hold hx_batch_stream_state_bytes bytes; a blob of another library build or saved under another
+   control is refused (-1, hx_last_error). */
 long long hx_batch_stream_state_bytes(const hx_batch *b);
 int hx_batch_get_stream_state(hx_batch *b, int i, void *dst);
 int hx_batch_set_stream_state(hx_batch *b, int i, const void *src);
@@ -163,13 +169,34 @@ int hx_batch_encode_f32_host_stats(hx_batch *b, const float *pcm, int nframes, u
 int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *head_out);
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
    there), 4 = the Huffman bits packed for a channel differ from the bits counted for it (an internal
-   consistency check of the two-wave packer).  0 = healthy.  Synchronises. */
+   consistency check of the two-wave packer), 8 = the gate of a pipelined submit gave up waiting at least
+   once (results are correct, the overlap was lost; hx_batch_gate_timeouts counts them).  0 = healthy.
+   Synchronises. */
 int hx_batch_status(hx_batch *b);
+int hx_batch_gate_timeouts(hx_batch *b);
 /* total frames / bytes emitted so far by stream i (synchronises) */
 HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int stream_index);
 /* mean device time of the dominant (allocator) kernel over the calls since the last query, in
    milliseconds, measured with HIP events on the launch stream; also returns the call count */
 float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls);
+
+/* ---- several GPUs of one node behind one handle (no reference equivalent) ----
+   nstreams independent streams in contiguous blocks over ndev devices (devices[0..ndev), or devices
+   0..ndev-1 when devices is NULL; ndev <= 0: every device present), block sizes differing by at most one;
+   one hx_batch per device, one host thread per device and call, nothing exchanged between devices.
+   Buffers as in the hx_batch_*_host calls, covering all nstreams streams; out_stride >= hx_multi_out_stride. */
+typedef struct hx_multi hx_multi;
+hx_multi *hx_multi_create(int ndev, const int *devices, int nstreams, const HX_E_CONTROL *ec, int shared_control, int max_frames);
+void hx_multi_destroy(hx_multi *m);
+int hx_multi_ndevices(const hx_multi *m);
+int hx_multi_nstreams(const hx_multi *m);
+int hx_multi_shard(const hx_multi *m, int k, int *device, int *first, int *count);   /* block k: its device and streams */
+hx_batch *hx_multi_batch(hx_multi *m, int k);                                        /* block k's batch, for the per-batch calls */
+long long hx_multi_out_stride(const hx_multi *m, int nframes);
+int hx_multi_encode_s16_host(hx_multi *m, const int16_t *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes);
+int hx_multi_encode_f32_host(hx_multi *m, const float *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes);
+int hx_multi_encode_f32_host_stats(hx_multi *m, const float *pcm, int nframes, unsigned char *out, long long out_stride, int *out_bytes, int *stats);
+int hx_multi_status(hx_multi *m);
 
 /* ---- test taps (tests only; synchronise) ---- */
 /* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg"; copies at most cap bytes, returns bytes */

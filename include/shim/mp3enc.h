@@ -44,6 +44,7 @@ class CMp3Enc
     void L3_audio_encode_info_ec(E_CONTROL *ec) { hx_enc_info_ec(h, (HX_E_CONTROL *) ec); }
     void L3_audio_encode_info_head(MPEG_HEAD *head) { hx_enc_info_head(h, (HX_MPEG_HEAD *) head); }
     void L3_audio_encode_info_string(char *s) { hx_enc_info_string(h, s); }
+    void out_stats() { hx_enc_out_stats(h); }           /* pub/mp3enc.h:141, test routine */
 
   private:
     static IN_OUT io(HX_IN_OUT x) { IN_OUT r; r.in_bytes = x.in_bytes; r.out_bytes = x.out_bytes; return r; }

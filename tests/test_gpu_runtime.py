@@ -1,0 +1,142 @@
+"""Host runtime around the kernels, on a real MI355X: multi-device dispatcher, checkpoint blob checks,
+argument validation of the host-buffer entry points, gate accounting, the bench's own multi-rank launch,
+and the streaming route of the command line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from hmp3_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+RHOS = [0.7, 0.0, 1.0, 0.3]
+
+
+def api():
+    from hmp3_amd import api as a
+    return a
+
+
+def oracle_bytes(kw, pcm, nfr):
+    enc = O.OracleEncoder(O.default_control(**kw))
+    return b"".join(enc.encode_s16(pcm[f * 1152:(f + 1) * 1152]) for f in range(nfr))
+
+
+def test_multi_device_dispatcher_blocks_streams_and_matches_oracle():
+    """hx_multi_*: 7 streams in 3 contiguous blocks (3 + 2 + 2), one host thread per block.  On a one-GPU box the
+    three blocks are three batches on device 0 - the host-side dispatch is the same."""
+    a = api()
+    kws = [dict(bitrate=64), dict(vbr_mnr=60), dict(bitrate=96, short_block_threshold=99999)]
+    S, F = 7, 10
+    pcm = np.stack([synth.stream_pcm(3100 + i, F, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    ctl = [a.default_control(**kws[i % 3]) for i in range(S)]
+    m = a.Multi(ctl, max_frames=F, devices=[0, 0, 0])
+    assert m.ndevices() == 3
+    assert [m.shard(k)[1:] for k in range(3)] == [(0, 3), (3, 2), (5, 2)]
+    first = m.encode_host(np.ascontiguousarray(pcm[:, :4 * 1152]))
+    second = m.encode_host(np.ascontiguousarray(pcm[:, 4 * 1152:]))     # 6 frames: state carried per block
+    assert m.status() == 0
+    for s in range(S):
+        assert first[s] + second[s] == oracle_bytes(kws[s % 3], pcm[s], F), s
+    m.close()
+    # more devices asked for than streams: one stream per block, the rest unused
+    m = a.Multi(a.default_control(bitrate=64), nstreams=2, max_frames=4, devices=[0, 0, 0, 0])
+    assert m.ndevices() == 2
+    m.close()
+    assert a.lib().hx_device_count() >= 1
+
+
+def test_checkpoint_blob_is_refused_under_another_configuration_or_size():
+    a = api()
+    b1 = a.Batch(a.default_control(bitrate=64), nstreams=1, max_frames=4)
+    b1.encode_host(synth.stream_pcm(1, 4)[None])
+    blob = b1.get_stream_state(0)
+    b2 = a.Batch(a.default_control(bitrate=96), nstreams=1, max_frames=4)       # other bitrate: other frame sizes / budgets
+    with pytest.raises(RuntimeError, match="different configuration"):
+        b2.set_stream_state(0, blob)
+    with pytest.raises(ValueError):
+        b1.set_stream_state(0, blob[:-8])
+    bad = bytearray(blob); bad[0] ^= 0xFF
+    with pytest.raises(RuntimeError, match="not a stream-state blob"):
+        b1.set_stream_state(0, bytes(bad))
+    b1.set_stream_state(0, blob)        # the genuine blob still goes in
+    b1.close(); b2.close()
+
+
+def test_host_entry_points_check_arguments_before_touching_the_device():
+    a = api()
+    L = a.lib()
+    b = a.Batch(a.default_control(bitrate=64), nstreams=2, max_frames=4)
+    pcm = np.zeros((2, 4 * 1152, 2), np.int16)
+    out = np.zeros((2, b.out_stride(4)), np.uint8)
+    nb = np.zeros(2, np.int32)
+    stride = b.out_stride(4)
+    for fn in (L.hx_batch_encode_s16_host, L.hx_batch_submit_s16_host):
+        assert fn(b.h, pcm.ctypes.data, 0, out.ctypes.data, stride, nb.ctypes.data) != 0        # nframes <= 0
+        assert fn(b.h, pcm.ctypes.data, -3, out.ctypes.data, stride, nb.ctypes.data) != 0
+        assert fn(b.h, pcm.ctypes.data, 5, out.ctypes.data, stride, nb.ctypes.data) != 0        # > max_frames
+        assert fn(b.h, None, 4, out.ctypes.data, stride, nb.ctypes.data) != 0
+        assert fn(b.h, pcm.ctypes.data, 4, None, stride, nb.ctypes.data) != 0
+        assert fn(b.h, pcm.ctypes.data, 4, out.ctypes.data, stride, None) != 0
+        assert fn(b.h, pcm.ctypes.data, 4, out.ctypes.data, 64, nb.ctypes.data) != 0           # out_stride too small
+        assert "out_stride" in a.last_error()
+    assert L.hx_batch_out_stride(None, 4) == 0 and L.hx_batch_status(None) == -1
+    # the batch is untouched: a good call gives the oracle's bytes
+    p = np.stack([synth.stream_pcm(41, 4), synth.stream_pcm(42, 4)])
+    got = b.encode_host(p)
+    for s in range(2):
+        assert got[s] == oracle_bytes(dict(bitrate=64), p[s], 4)
+    assert b.status() == 0 and b.gate_timeouts() == 0
+    b.close()
+    with pytest.raises(RuntimeError, match="32 Mi"):
+        a.Batch(a.default_control(bitrate=64), nstreams=1 << 20, max_frames=64)
+
+
+def _bench(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_two_ranks_encode_disjoint_stream_blocks():
+    """bench.py --gpus 2 launches two ranks itself; on this one-GPU box both use GPU 0 (--share-gpu) and the
+    process group runs on gloo.  Each rank encodes its own block of streams and rank 0 verifies against the oracle."""
+    rc, line, err = _bench(["--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "24", "--frames", "8", "--steps", "2", "--warmup", "1",
+                            "--verify", "6", "--no-cpu-baseline", "--no-worst-case"])
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["kernel_status"] == 0
+    assert line["verified_streams"] == 6 and line["verify"]["first_mismatch"] is None
+    assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_bench_configs_verify_against_oracle_at_reduced_size(cfg):
+    rc, line, err = _bench(["--config", str(cfg), "--streams", "48", "--frames", "12", "--steps", "2", "--warmup", "1", "--verify", "12",
+                            "--no-cpu-baseline", "--no-worst-case"])
+    assert rc == 0, err[-2000:]
+    assert line["config"]["baseline_config"] == cfg and line["kernel_status"] == 0
+    assert line["verified_streams"] == 12, line["verify"]
+
+
+@pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr50_s24_44k", "cli_lsf_vbr50_f32_24k", "cli_rifx_cbr64_s16_44k"])
+def test_cli_streams_from_a_pipe_with_bounded_buffers(name, tmp_path):
+    """`hmp3amd - out.mp3`: the input arrives on a pipe and is encoded frame by frame through a sliding window
+    (memory independent of the input length); the file equals the one the reference CLI wrote from the WAV."""
+    sys.path.insert(0, GOLD)
+    import make_golden_cli as M
+    seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
+    wav, mp3 = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3")
+    M.write_wav(wav, M.case_pcm(name), sr, as_float, M.CONTAINER.get(name))
+    cli = os.path.join(ROOT, "hmp3_amd", "hmp3amd")
+    with open(wav, "rb") as f:
+        r = subprocess.run([cli, "-", mp3] + flags + ["-EC"], stdin=f, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    assert b"ec->samprate" in r.stderr            # -EC prints the settings in use
+    assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()

@@ -54,3 +54,32 @@ def test_two_ranks_gloo_cover_all_streams_once():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["tmax"] == 1.5
     assert all(v > 0 for v in ret["sizes"]) and len(ret["sizes"]) == 6
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` starts two ranks by itself (no torchrun); here without a GPU:
+    rendezvous, sharding and the reporting path only (--dry-run), process group on gloo"""
+    rc, line, err = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo"])
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["streams_total"] == 2 * 1024
+    assert line["max_time_token"] == 2.0            # max over ranks of (1 + rank)
+
+
+def test_bench_rejects_world_size_that_differs_from_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
