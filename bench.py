@@ -356,7 +356,10 @@ def main():
             dt = float(tt.item())
         m = {"dt": dt, "status": batch.status(), "out_total": int(nbytes.sum().item())}
         m["k_ms"], m["k_calls"] = batch.alloc_kernel_ms()
-        m["gate_timeouts"] = batch.gate_timeouts() if hasattr(batch, "gate_timeouts") else 0
+        try:
+            m["gate_timeouts"] = batch.gate_timeouts()
+        except AttributeError:      # an older build of the library (HMP3AMD_LIB)
+            m["gate_timeouts"] = None
         if verify_n > 0 and rank == 0:
             rs = np.random.RandomState(12345 + args.config)
             ids = sorted(rs.choice(S, size=min(verify_n, S), replace=False).tolist())
@@ -432,7 +435,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(res), flush=True)
-        failed = m["status"] != 0 or ("verified" in m and m["verified"] != m["verify_n"])
+        # status bit 8 = a gate gave up waiting: overlap lost, results intact (reported as gate_timeouts)
+        failed = (m["status"] & ~8) != 0 or ("verified" in m and m["verified"] != m["verify_n"])
     else:
         failed = False
     if dist is not None:

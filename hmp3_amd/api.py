@@ -128,21 +128,22 @@ def lib():
         L.hx_batch_encode_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.hx_batch_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
         L.hx_batch_status.argtypes = [C.c_void_p]
-        L.hx_batch_gate_timeouts.argtypes = [C.c_void_p]
-        L.hx_multi_create.restype = C.c_void_p
-        L.hx_multi_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
-        L.hx_multi_destroy.argtypes = [C.c_void_p]
-        L.hx_multi_ndevices.argtypes = [C.c_void_p]
-        L.hx_multi_nstreams.argtypes = [C.c_void_p]
-        L.hx_multi_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.hx_multi_batch.restype = C.c_void_p
-        L.hx_multi_batch.argtypes = [C.c_void_p, C.c_int]
-        L.hx_multi_out_stride.restype = C.c_longlong
-        L.hx_multi_out_stride.argtypes = [C.c_void_p, C.c_int]
-        L.hx_multi_encode_s16_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
-        L.hx_multi_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
-        L.hx_multi_encode_f32_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
-        L.hx_multi_status.argtypes = [C.c_void_p]
+        if hasattr(L, "hx_multi_create"):           # absent from older builds selected through HMP3AMD_LIB (A/B timing runs)
+            L.hx_batch_gate_timeouts.argtypes = [C.c_void_p]
+            L.hx_multi_create.restype = C.c_void_p
+            L.hx_multi_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+            L.hx_multi_destroy.argtypes = [C.c_void_p]
+            L.hx_multi_ndevices.argtypes = [C.c_void_p]
+            L.hx_multi_nstreams.argtypes = [C.c_void_p]
+            L.hx_multi_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            L.hx_multi_batch.restype = C.c_void_p
+            L.hx_multi_batch.argtypes = [C.c_void_p, C.c_int]
+            L.hx_multi_out_stride.restype = C.c_longlong
+            L.hx_multi_out_stride.argtypes = [C.c_void_p, C.c_int]
+            L.hx_multi_encode_s16_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+            L.hx_multi_encode_f32_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+            L.hx_multi_encode_f32_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+            L.hx_multi_status.argtypes = [C.c_void_p]
         L.hx_batch_frames_bytes.argtypes = [C.c_void_p, C.c_int]
         L.hx_batch_frames_bytes.restype = IntPair
         L.hx_batch_alloc_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -299,6 +300,8 @@ class Multi:
     def __init__(self, controls, nstreams=None, max_frames=256, ndev=0, devices=None):
         L = lib()
         dv = (C.c_int * len(devices))(*devices) if devices else None
+        if devices:
+            ndev = len(devices)
         if isinstance(controls, EControl):
             self.n = int(nstreams)
             self._ec = controls

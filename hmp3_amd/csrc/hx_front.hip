@@ -1,6 +1,6 @@
 // hx_front.hip - front-end kernels of the batched MP3 encoder for MI355X (gfx950):
 //   k_dcfilter   K0  optional input DC blocker, sequential per channel   (filter2.c:116-144)
-//   k_polyphase  K1  int16 / fp32 PCM -> 32 x 18 subband samples per granule (replaces sbt.c:57-310)
+//   k_polyphase  K1  int16 / fp32 PCM -> 32 x 18 subband samples per granule (the stage of sbt.c:57-310)
 //   k_attack_eng K2a subband energies in mB for the transient detector  (detect.c:80-101)
 //   k_attack_flg K2b attack metric for both "previous granule short" cases (detect.c:103-141)
 //   k_blocktype  K2c per-stream block-type state machine                (mp3enc.cpp:1398-1440)
@@ -16,39 +16,34 @@
 #define K1_NS (480 + 576 * K1_GPB)      // staged samples
 #define K1_LDS (K1_NS + (K1_NS >> 5) + 1)
 
-template <int M, int N>
-__device__ __forceinline__ void dct_split(const float *x, float *f)
-{
-    constexpr int H = N / 2;
+// N-point DCT of the analysis filterbank by odd / even decimation:
+//   X[j], X[N-1-j] = E[j] +- tw_N[j] * O[j]   with   E = DCT_{N/2}(x[0], x[2], ...),  O = DCT_{N/2}(u),
+//   u[i] = x[2i+1] - u[i+1],  u[N/2-1] = x[N-1]   (running difference of the odd samples from the top)
+// tw_N[j] = 2 cos(pi (2j+1) / 2N) sits at tw[N/2 + j].  Everything stays in registers: the recursion is
+// resolved at compile time into straight-line code, depth first.  Each sum is one rounding, in the order
+// written here, which is also the reference's (sbt.c:134-259), so the subband samples agree bit for bit.
+template <int N> struct AnalysisDct {
+    static __device__ __forceinline__ void run(const float *x, float *X, const float *tw)
+    {
+        constexpr int H = N / 2;
+        float even[H], u[H], E[H], O[H];
+        u[H - 1] = x[N - 1];
+        even[H - 1] = x[N - 2];
 #pragma unroll
-    for (int blk = 0; blk < M; blk++) {
-        const float *xx = x + blk * N;
-        float *ff = f + blk * N;
-        ff[H + H - 1] = xx[N - 1];
-        ff[H - 1] = xx[N - 2];
-#pragma unroll
-        for (int i = H - 2; i >= 0; i--) {
-            ff[H + i] = xx[2 * i + 1] - ff[H + i + 1];
-            ff[i] = xx[2 * i];
-        }
-    }
-}
-
-template <int M, int N>
-__device__ __forceinline__ void dct_bfly(const float *x, float *f, const float *c)
-{
-    constexpr int H = N / 2;
-#pragma unroll
-    for (int blk = 0; blk < M; blk++) {
+        for (int i = H - 2; i >= 0; i--) { u[i] = x[2 * i + 1] - u[i + 1]; even[i] = x[2 * i]; }
+        AnalysisDct<H>::run(even, E, tw);
+        AnalysisDct<H>::run(u, O, tw);
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            float tmp = c[j] * x[blk * N + j + H];
-            float t = x[blk * N + j];
-            f[blk * N + j] = t + tmp;
-            f[blk * N + N - 1 - j] = t - tmp;
+            const float r = tw[H + j] * O[j];
+            X[j] = E[j] + r;
+            X[N - 1 - j] = E[j] - r;
         }
     }
-}
+};
+template <> struct AnalysisDct<1> {
+    static __device__ __forceinline__ void run(const float *x, float *X, const float *) { X[0] = x[0]; }
+};
 
 // One lane = one time slot: 512-tap window folded to 32 values, then the 32-point DCT.
 // A workgroup stages the interleaved stereo PCM of K1_GPB granules (plus 480 samples of history)
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     const float *P = xs + (base + (base >> 5) - 526);       // P[526 - pad(off)] = sample of age off
 #define XS(off) P[526 - ((off) + ((off) >> 5))]
     // window taps from LDS in use order: four per 16-byte broadcast read
-    float a[32], b[32];
+    float b[32], X[32];
     {
         const float4 *w4 = reinterpret_cast<const float4 *>(wr);
         float s1 = 0.0f;
@@ -155,22 +150,10 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
         b[k] = s1 + s2;
     }
 #undef XS
-    const float *c = p->dct_coef;
-    dct_split<1, 32>(b, a);
-    dct_split<2, 16>(a, b);
-    dct_split<4, 8>(b, a);
-    dct_split<8, 4>(a, b);
-    dct_bfly<16, 2>(b, a, c + 30);
-    dct_bfly<8, 4>(a, b, c + 28);
-    dct_bfly<4, 8>(b, a, c + 24);
-    dct_bfly<2, 16>(a, b, c + 16);
+    AnalysisDct<32>::run(b, X, p->dct_tw);
     float *out = sb + ((long long) (s * 2 + ch) * SG + (g0 + gl + 3)) * 576 + t;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        float tmp = c[k] * b[k + 16];
-        out[18 * k] = b[k] + tmp;
-        out[18 * (31 - k)] = b[k] - tmp;
-    }
+    for (int k = 0; k < 32; k++) out[18 * k] = X[k];
 }
 
 // energies of subbands 4..17 (MPEG-2 LSF rates: 8..27, detect.c:147-196) per slot pair, as mB.
@@ -270,100 +253,71 @@ __global__ void k_blocktype(HxStream *__restrict__ st, const unsigned char *__re
     }
 }
 
-// 18-point transform of the folded, windowed input (reference emdct.c:104-188)
-__device__ __forceinline__ void mdct18(const HxParams *p, const float *f, float *y)
-{
-    const float *w = p->m18_w, *w2 = p->m18_w2;
-    const float (*c)[4] = p->m18_c;
-    float a[9], b[9], g1, g2, ap, bp, a8p, b8p;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        g1 = w[q] * f[q];
-        g2 = w[17 - q] * f[17 - q];
-        ap = g1 + g2;
-        bp = w2[q] * (g1 - g2);
-        g1 = w[8 - q] * f[8 - q];
-        g2 = w[9 + q] * f[9 + q];
-        a8p = g1 + g2;
-        b8p = w2[8 - q] * (g1 - g2);
-        a[q] = ap + a8p;
-        a[5 + q] = ap - a8p;
-        b[q] = bp + b8p;
-        b[5 + q] = bp - b8p;
-    }
-    g1 = w[4] * f[4];
-    g2 = w[13] * f[13];
-    a[4] = g1 + g2;
-    b[4] = w2[4] * (g1 - g2);
-    y[0] = 0.5f * (a[0] + a[1] + a[2] + a[3] + a[4]);
-    y[1] = 0.5f * (b[0] + b[1] + b[2] + b[3] + b[4]);
-    y[2] = c[1][0] * a[5] + c[1][1] * a[6] + c[1][2] * a[7] + c[1][3] * a[8];
-    y[3] = c[1][0] * b[5] + c[1][1] * b[6] + c[1][2] * b[7] + c[1][3] * b[8] - y[1];
-    y[1] = y[1] - y[0];
-    y[2] = y[2] - y[1];
-    y[4] = c[2][0] * a[0] + c[2][1] * a[1] + c[2][2] * a[2] + c[2][3] * a[3] - a[4];
-    y[5] = c[2][0] * b[0] + c[2][1] * b[1] + c[2][2] * b[2] + c[2][3] * b[3] - b[4] - y[3];
-    y[3] = y[3] - y[2];
-    y[4] = y[4] - y[3];
-    y[6] = c[3][0] * (a[5] - a[7] - a[8]);
-    y[7] = c[3][0] * (b[5] - b[7] - b[8]) - y[5];
-    y[5] = y[5] - y[4];
-    y[6] = y[6] - y[5];
-    y[8] = c[4][0] * a[0] + c[4][1] * a[1] + c[4][2] * a[2] + c[4][3] * a[3] + a[4];
-    y[9] = c[4][0] * b[0] + c[4][1] * b[1] + c[4][2] * b[2] + c[4][3] * b[3] + b[4] - y[7];
-    y[7] = y[7] - y[6];
-    y[8] = y[8] - y[7];
-    y[10] = c[5][0] * a[5] + c[5][1] * a[6] + c[5][2] * a[7] + c[5][3] * a[8];
-    y[11] = c[5][0] * b[5] + c[5][1] * b[6] + c[5][2] * b[7] + c[5][3] * b[8] - y[9];
-    y[9] = y[9] - y[8];
-    y[10] = y[10] - y[9];
-    y[12] = 0.5f * (a[0] + a[2] + a[3]) - a[1] - a[4];
-    y[13] = 0.5f * (b[0] + b[2] + b[3]) - b[1] - b[4] - y[11];
-    y[11] = y[11] - y[10];
-    y[12] = y[12] - y[11];
-    y[14] = c[7][0] * a[5] + c[7][1] * a[6] + c[7][2] * a[7] + c[7][3] * a[8];
-    y[15] = c[7][0] * b[5] + c[7][1] * b[6] + c[7][2] * b[7] + c[7][3] * b[8] - y[13];
-    y[13] = y[13] - y[12];
-    y[14] = y[14] - y[13];
-    y[16] = c[8][0] * a[0] + c[8][1] * a[1] + c[8][2] * a[2] + c[8][3] * a[3] + a[4];
-    y[17] = c[8][0] * b[0] + c[8][1] * b[1] + c[8][2] * b[2] + c[8][3] * b[3] + b[4] - y[15];
-    y[15] = y[15] - y[14];
-    y[16] = y[16] - y[15];
-    y[17] = y[17] - y[16];
-}
+// ---- MDCT kernels ------------------------------------------------------------------------------------
+// An N-point kernel (N = 18 for long blocks, 6 for each short window) maps the folded, windowed input f to
+// N spectral lines in three steps:
+//   1. twiddle and pair the inputs:  g_i = pre[i] f[i];  s_i = g_i + g_{N-1-i};  d_i = odd[i] (g_i - g_{N-1-i})
+//   2. an N/2-point cosine transform C of each half:  S = C(s),  D = C(d)
+//   3. un-twist:  T_0 = D_0, T_k = D_k - T_{k-1};  y = (S_0, T_0, S_1, T_1, ...) with every element after the
+//      first reduced by its finished predecessor.
+// The cosine transforms are written out below; sums run left to right.  Operation order equals the
+// reference's (emdct.c:104-303), hence bit-identical spectra.
 
-// three 6-point transforms of a short block (reference emdct.c:252-303); y[6*w + k]
-__device__ __forceinline__ void mdct6x3(const HxParams *p, const float *f, float *y)
+// ((c0 v0 + c1 v1) + c2 v2) + c3 v3
+__device__ __forceinline__ float dot4(const float *c, const float *v) { return c[0] * v[0] + c[1] * v[1] + c[2] * v[2] + c[3] * v[3]; }
+
+struct Cos9 {       // 9-point: the input is folded once more into 5 sums (-> even outputs) and 4 differences (-> odd)
+    static constexpr int n = 9;
+    static __device__ __forceinline__ void run(const HxParams *p, const float *u, float *X)
+    {
+        float e[4], o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { e[q] = u[q] + u[8 - q]; o[q] = u[q] - u[8 - q]; }
+        const float mid = u[4];
+        X[0] = 0.5f * (e[0] + e[1] + e[2] + e[3] + mid);
+        X[6] = 0.5f * (e[0] + e[2] + e[3]) - e[1] - mid;
+        X[3] = p->dct9_k3 * (o[0] - o[2] - o[3]);
+        X[2] = dot4(p->dct9_even[0], e) - mid;
+        X[4] = dot4(p->dct9_even[1], e) + mid;
+        X[8] = dot4(p->dct9_even[2], e) + mid;
+        X[1] = dot4(p->dct9_odd[0], o);
+        X[5] = dot4(p->dct9_odd[1], o);
+        X[7] = dot4(p->dct9_odd[2], o);
+    }
+};
+
+struct Cos3 {       // 3-point
+    static constexpr int n = 3;
+    static __device__ __forceinline__ void run(const HxParams *p, const float *u, float *X)
+    {
+        const float e = u[0] + u[2];
+        X[0] = e + u[1];
+        X[1] = p->dct3_k * (u[0] - u[2]);
+        X[2] = e - u[1] - u[1];
+    }
+};
+
+template <class Cos>
+__device__ __forceinline__ void mdct_kernel(const HxParams *p, const float *pre, const float *odd, const float *f, float *y)
 {
-    const float *v = p->m6_v, *v2 = p->m6_v2;
-    const float c87 = p->m6_c87;
-    float a[18];
+    constexpr int H = Cos::n, N = 2 * H;
+    float s[H], d[H], S[H], D[H];
 #pragma unroll
-    for (int w = 0; w < 3; w++)
+    for (int i = 0; i < H; i++) {
+        const float lo = pre[i] * f[i], hi = pre[N - 1 - i] * f[N - 1 - i];
+        s[i] = lo + hi;
+        d[i] = odd[i] * (lo - hi);
+    }
+    Cos::run(p, s, S);
+    Cos::run(p, d, D);
+    float twist = D[0];
+    y[0] = S[0];
+    y[1] = twist - y[0];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            float g1 = v[q] * f[6 * w + q];
-            float g2 = v[5 - q] * f[6 * w + 5 - q];
-            a[6 * w + q] = g1 + g2;
-            a[6 * w + 3 + q] = v2[q] * (g1 - g2);
-        }
-#pragma unroll
-    for (int w = 0; w < 3; w++) {
-        const float *aa = a + 6 * w;
-        float *c = y + 6 * w;
-        float a02 = (aa[0] + aa[2]);
-        float b02 = (aa[3] + aa[5]);
-        c[0] = a02 + aa[1];
-        c[1] = b02 + aa[4];
-        c[2] = c87 * (aa[0] - aa[2]);
-        c[3] = c87 * (aa[3] - aa[5]) - c[1];
-        c[1] = c[1] - c[0];
-        c[2] = c[2] - c[1];
-        c[4] = a02 - aa[1] - aa[1];
-        c[5] = b02 - aa[4] - aa[4] - c[3];
-        c[3] = c[3] - c[2];
-        c[4] = c[4] - c[3];
-        c[5] = c[5] - c[4];
+    for (int k = 1; k < H; k++) {
+        twist = D[k] - twist;
+        y[2 * k] = S[k] - y[2 * k - 1];
+        y[2 * k + 1] = twist - y[2 * k];
     }
 }
 
@@ -573,7 +527,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
                 f[j] = w[26 - j] * p2[8 - j] + w[27 + j] * p2[9 + j];
                 f[9 + j] = w[j] * p1[j] + w[17 - j] * p1[17 - j];
             }
-            mdct18(p, f, y);
+            mdct_kernel<Cos9>(p, p->mdct_pre18, p->mdct_odd18, f, y);
         } else {        // short: three overlapping 12-tap windows (reference hwin.c:228-278)
             const float *w = p->win[2];
 #pragma unroll
@@ -585,7 +539,8 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
                 f[12 + q] = w[8 - q] * p2[8 - q] + w[9 + q] * p2[9 + q];
                 f[15 + q] = w[q] * p2[q] + w[5 - q] * p2[5 - q];
             }
-            mdct6x3(p, f, y);
+#pragma unroll
+            for (int w = 0; w < 3; w++) mdct_kernel<Cos3>(p, p->mdct_pre6, p->mdct_odd6, f + 6 * w, y + 6 * w);
         }
     }
     // alias reduction between subband k (lane) and k+1: x[17-i] with next lane's x[i]
@@ -686,18 +641,19 @@ __global__ void k_dcfilter(const int16_t *__restrict__ pcm, const float *__restr
     ss->dc[ch] = d;
 }
 
-// Gate of a pipelined submit (hx_batch_submit_*): holds the stream it is launched on until the
-// allocator kernel of the previous call has retired `need` of its streams, so that the front-end
-// kernels behind it start in that kernel's tail instead of competing with its start.  The counter
-// runs over all launches of the batch and may wrap: `base` is its value when the previous launch
-// began, and the distance is compared as unsigned.  Gives up after ~50 ms (late is harmless, a hang
-// is not) and counts that in *timeouts, so the caller can see that the overlap degraded.
-__global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts)
+// Gate of a pipelined submit (hx_batch_submit_*): holds the stream it is launched on until `need` workgroups of
+// the previous call's allocator kernel have started, i.e. until that kernel occupies its share of the chip.
+// The front-end kernels behind the gate then queue for the slots that finishing streams free, and run in the
+// allocator kernel's tail; released earlier they would take LDS away from allocator workgroups that have not
+// started yet.  The counter runs over all launches of the batch and may wrap: `base` is its value when the
+// previous launch began, and the distance is compared as unsigned.  Gives up after ~50 ms (late is harmless, a
+// hang is not) and counts that in *timeouts, so the caller can see that the overlap degraded.
+__global__ void k_gate(const unsigned *started_counter, unsigned base, unsigned need, int *timeouts)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();        // 100 MHz
-    while (__hip_atomic_load(done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base < need) {
-        __builtin_amdgcn_s_sleep(127);
+    while (__hip_atomic_load(started_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base < need) {
+        __builtin_amdgcn_s_sleep(32);
         if (wall_clock64() - t0 > 5000000LL) { atomicAdd(timeouts, 1); break; }
     }
 }

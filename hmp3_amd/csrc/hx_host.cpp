@@ -95,47 +95,70 @@ static int sfbl_limit(int sr, int band_limit)
     return i > 21 ? 21 : i;
 }
 
+// ---- transform constants ---------------------------------------------------------------------------
+// Each value is formed in double from its closed form and rounded to float once; products of angles are
+// taken left to right as written, so the float tables equal the reference encoder's bit for bit
+// (tests/test_host_and_abi.py compares them with the oracle's).
+static const double kPi = 4.0 * atan(1.0);
+
+// ISO 11172-3 2.4.3.4.10.3 block window of type bt (0 normal, 1 start, 2 short, 3 stop) at n = 0..35
+static float iso_block_window(int bt, int n)
+{
+    const double lng = sin(kPi / 36 * (n + 0.5));
+    switch (bt) {
+    case 0: return (float) lng;
+    case 1: return n < 18 ? (float) lng : (n < 24 ? 1.0f : (n < 30 ? (float) sin(kPi / 12 * (n + 0.5 - 18)) : 0.0f));
+    case 3: return n < 6 ? 0.0f : (n < 12 ? (float) sin(kPi / 12 * (n + 0.5 - 6)) : (n < 18 ? 1.0f : (float) lng));
+    default: return n < 12 ? (float) sin(kPi / 12 * (n + 0.5)) : 0.0f;
+    }
+}
+
+// input twiddle 2 cos(pi (2q+1) / 4N) of an N-point MDCT kernel, and the odd half's 2 cos(pi (2q+1) / 2N)
+static float mdct_twiddle(int N, int q, int doubled)
+{
+    const double t = kPi / (4 * N);
+    return (float) (2.0 * cos((doubled ? 2 * t : t) * (2 * q + 1)));
+}
+// cos(pi k (2q+1) / N): entry (k, q) of the N/2-point cosine transform, k even numbered as 2k' in the kernel
+static float dct_entry(int N, int k2, int q)
+{
+    const double t = kPi / (2 * N);
+    return (float) cos(t * k2 * (2 * q + 1));
+}
+
 static void transform_tables(HxParams *p)
 {
-    static const float Ci[8] = {-0.6f, -0.535f, -0.33f, -0.185f, -0.095f, -0.041f, -0.0142f, -0.0037f};
-    double pi = 4.0 * atan(1.0), t;
-    int k = 0;
-    for (int n = 16; n >= 1; n /= 2)
-        for (int q = 0; q < n; q++, k++) p->dct_coef[k] = (float) (2.0 * cos((pi / (4 * n)) * (2 * q + 1)));
+    // analysis filterbank: twiddles of the 32-point DCT's five recursion levels
+    p->dct_tw[0] = 0.0f;
+    for (int N = 2; N <= 32; N *= 2)
+        for (int j = 0; j < N / 2; j++) p->dct_tw[N / 2 + j] = (float) (2.0 * cos((kPi / (2 * N)) * (2 * j + 1)));
+    // alias reduction: cs = 1 / sqrt(1 + c^2), ca = c / sqrt(1 + c^2) for the eight ISO butterfly constants
+    static const float c_iso[8] = {-0.6f, -0.535f, -0.33f, -0.185f, -0.095f, -0.041f, -0.0142f, -0.0037f};
     for (int i = 0; i < 8; i++) {
-        float c2 = Ci[i] * Ci[i];
-        p->csa[0][i] = (float) (1.0 / sqrt(1.0 + c2));
-        p->csa[1][i] = (float) (Ci[i] / sqrt(1.0 + c2));
+        const float c = c_iso[i], cc = c * c;
+        p->csa[0][i] = (float) (1.0 / sqrt(1.0 + cc));
+        p->csa[1][i] = (float) (c / sqrt(1.0 + cc));
     }
-    t = pi / 72;
-    for (int q = 0; q < 18; q++) p->m18_w[q] = (float) (2.0 * cos(t * (2 * q + 1)));
-    for (int q = 0; q < 9; q++) p->m18_w2[q] = (float) (2.0 * cos(2 * t * (2 * q + 1)));
-    t = pi / 36;
-    for (int kk = 0; kk < 9; kk++)
-        for (int q = 0; q < 4; q++) p->m18_c[kk][q] = (float) cos(t * (2 * kk) * (2 * q + 1));
-    t = pi / 24;
-    for (int q = 0; q < 6; q++) p->m6_v[q] = (float) (2.0 * cos(t * (2 * q + 1)));
-    for (int q = 0; q < 3; q++) p->m6_v2[q] = (float) (2.0 * cos(2 * t * (2 * q + 1)));
-    t = pi / 12;
-    p->m6_c87 = (float) cos(t * 2 * 1);
-    for (int q = 0; q < 6; q++) p->m6_v[q] = p->m6_v[q] / 2.0f;
-    p->m6_c87 = 2.0f * p->m6_c87;
-    float (*w)[36] = p->win;
-    for (int i = 0; i < 36; i++) w[0][i] = (float) sin(pi / 36 * (i + 0.5));
-    for (int i = 0; i < 18; i++) w[1][i] = (float) sin(pi / 36 * (i + 0.5));
-    for (int i = 18; i < 24; i++) w[1][i] = 1.0f;
-    for (int i = 24; i < 30; i++) w[1][i] = (float) sin(pi / 12 * (i + 0.5 - 18));
-    for (int i = 30; i < 36; i++) w[1][i] = 0.0f;
-    for (int i = 0; i < 6; i++) w[3][i] = 0.0f;
-    for (int i = 6; i < 12; i++) w[3][i] = (float) sin(pi / 12 * (i + 0.5 - 6));
-    for (int i = 12; i < 18; i++) w[3][i] = 1.0f;
-    for (int i = 18; i < 36; i++) w[3][i] = (float) sin(pi / 36 * (i + 0.5));
-    for (int i = 0; i < 12; i++) w[2][i] = (float) sin(pi / 12 * (i + 0.5));
-    for (int i = 12; i < 36; i++) w[2][i] = 0.0f;
-    for (int j = 0; j < 4; j++) { if (j == 2) continue; for (int i = 9; i < 36; i++) w[j][i] = -w[j][i]; }
-    for (int i = 3; i < 12; i++) w[2][i] = -w[2][i];
-    for (int j = 0; j < 4; j++) { if (j == 2) continue; for (int i = 0; i < 36; i++) w[j][i] = (1.0f / 9.0f) * w[j][i]; }
-    for (int i = 0; i < 36; i++) w[2][i] = (1.0f / 3.0f) * w[2][i];
+    // block windows with the sign pattern of the 36 -> 18 (12 -> 6) fold and the 1/9 (1/3) gain of the kernel folded in
+    for (int bt = 0; bt < 4; bt++)
+        for (int n = 0; n < 36; n++) {
+            const float w = iso_block_window(bt, n);
+            const bool neg = (bt == 2) ? (n >= 3 && n < 12) : (n >= 9);
+            p->win[bt][n] = (bt == 2 ? 1.0f / 3.0f : 1.0f / 9.0f) * (neg ? -w : w);
+        }
+    // MDCT kernels
+    for (int q = 0; q < 18; q++) p->mdct_pre18[q] = mdct_twiddle(18, q, 0);
+    for (int q = 0; q < 9; q++) p->mdct_odd18[q] = mdct_twiddle(18, q, 1);
+    static const int even_rows[3] = {2, 4, 8}, odd_rows[3] = {1, 5, 7};
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 4; q++) {
+            p->dct9_even[r][q] = dct_entry(18, 2 * even_rows[r], q);
+            p->dct9_odd[r][q] = dct_entry(18, 2 * odd_rows[r], q);
+        }
+    p->dct9_k3 = dct_entry(18, 2 * 3, 0);
+    for (int q = 0; q < 6; q++) p->mdct_pre6[q] = mdct_twiddle(6, q, 0) / 2.0f;     // the short kernel carries half the gain here ...
+    for (int q = 0; q < 3; q++) p->mdct_odd6[q] = mdct_twiddle(6, q, 1);
+    p->dct3_k = 2.0f * dct_entry(6, 2, 0);                                           // ... and twice on its middle output
 }
 
 static float f_to_bark(float f)

@@ -49,10 +49,13 @@ struct HxParams {
     int look_log_cbwmb[22];
     float rnBand_l[22];
     unsigned char band_of_line[576];    // sfb index of each MDCT line (allocator's band table)
-    float dct_coef[32];
+    // 32-point analysis DCT: twiddles 2 cos(pi (2j+1) / 2N) of the size-N step at [N/2 + j] (heap order; [0] unused)
+    float dct_tw[32];
     float win[4][36], csa[2][8];
-    float m18_w[18], m18_w2[9], m18_c[9][4];
-    float m6_v[6], m6_v2[3], m6_c87;
+    // N-point MDCT kernels (N = 18 long, 6 short): input twiddles, twiddles of the odd half, and the rows of the
+    // N/2-point cosine transform that are not plain sums (9-point: outputs 2, 4, 8 / 1, 5, 7 / the factor of output 3)
+    float mdct_pre18[18], mdct_odd18[9], dct9_even[3][4], dct9_odd[3][4], dct9_k3;
+    float mdct_pre6[6], mdct_odd6[3], dct3_k;
     HxPsyTab psyL;
     HxPsyTab psyS;                      // short blocks: rows from w[0]
     float look_gain[128], look_34igain[128], look_ix43[256];

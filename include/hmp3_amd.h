@@ -140,8 +140,9 @@ int hx_batch_submit_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, u
 int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,
                                long long out_stride, int *d_out_bytes, void *stream);
 int hx_batch_wait(hx_batch *b, void *stream);
-/* a submit's front end is held back until this share (percent, default 90) of the previous call's streams has
-   left the allocator kernel, so that it runs in that kernel's tail; 0 starts it at once */
+/* a submit's front end is held back until the previous call's allocator kernel occupies its share of the chip:
+   until this percentage (default 90) of the workgroups the device can hold at once have started.  It then
+   queues for the slots that finishing streams free and runs in that kernel's tail; 0 releases it at once. */
 void hx_batch_set_gate(hx_batch *b, int percent);
 /* The same pipelining for host buffers: the PCM of call n+1 crosses PCIe while call n is encoded and the
    bitstream of call n while call n+1 is.  pcm must stay unchanged, and out / out_bytes are undefined, until

@@ -850,6 +850,7 @@ long long hxo_debug_table(const hxo_encoder *e, const char *name, void *dst, lon
     TAB("psy_w", p->psyL.w) TAB("psy_cnt", p->psyL.cnt) TAB("psy_off", p->psyL.off) TAB("psy_nsum", p->psyL.nsum)
     TAB("psy_npart", p->psyL.npart) TAB("dct_coef", p->dct_coef) TAB("win", p->win) TAB("csa", p->csa)
     TAB("m18_w", p->m18_w) TAB("m18_w2", p->m18_w2) TAB("m18_c", p->m18_c)
+    TAB("m6_v", p->m6_v) TAB("m6_v2", p->m6_v2) TAB("m6_c87", p->m6_c87)
     TAB("look_gain", p->look_gain) TAB("look_34igain", p->look_34igain) TAB("look_ix43", p->look_ix43)
     TAB("look_log_cbwmb", p->look_log_cbwmb) TAB("nBand_l", p->nBand_l) TAB("startBand_l", p->startBand_l)
     TAB("nsf", p->nsf) TAB("taperNT", p->taperNT) TAB("head", p->head) TAB("ec", p->ec)

@@ -110,7 +110,7 @@ def test_bench_two_ranks_encode_disjoint_stream_blocks():
     process group runs on gloo.  Each rank encodes its own block of streams and rank 0 verifies against the oracle."""
     rc, line, err = _bench(["--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "24", "--frames", "8", "--steps", "2", "--warmup", "1",
                             "--verify", "6", "--no-cpu-baseline", "--no-worst-case"])
-    assert rc == 0, err[-2000:]
+    assert rc == 0, (line, err[-2000:])
     assert line["n_gpus"] == 2 and line["kernel_status"] == 0
     assert line["verified_streams"] == 6 and line["verify"]["first_mismatch"] is None
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
@@ -120,7 +120,7 @@ def test_bench_two_ranks_encode_disjoint_stream_blocks():
 def test_bench_configs_verify_against_oracle_at_reduced_size(cfg):
     rc, line, err = _bench(["--config", str(cfg), "--streams", "48", "--frames", "12", "--steps", "2", "--warmup", "1", "--verify", "12",
                             "--no-cpu-baseline", "--no-worst-case"])
-    assert rc == 0, err[-2000:]
+    assert rc == 0, (line, err[-2000:])
     assert line["config"]["baseline_config"] == cfg and line["kernel_status"] == 0
     assert line["verified_streams"] == 12, line["verify"]
 

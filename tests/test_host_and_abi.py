@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "hmp3_amd", "libhmp3amd.so")
 pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="hmp3_amd/libhmp3amd.so not built (hmp3_amd/build.sh)")
 
-TABLES = ["psy_w", "psy_cnt", "psy_off", "psy_nsum", "psy_npart", "win", "csa", "m18_w", "m18_w2", "m18_c",
+TABLES = ["psy_w", "psy_cnt", "psy_off", "psy_nsum", "psy_npart", "win", "csa",
           "look_gain", "look_34igain", "look_ix43", "look_log_cbwmb", "nBand_l", "startBand_l", "nsf", "taperNT",
           "head", "ec", "scalars"]
 CONFIGS = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000),
@@ -49,6 +49,39 @@ def test_host_tables_equal_oracle_tables(kw):
         nb = api.lib().hx_debug_host_table(C.byref(eg), n.encode(), b.ctypes.data, b.nbytes)
         assert na == nb and na > 0, n
         assert np.array_equal(a[:na], b[:nb]), "table %s differs from the oracle's" % n
+
+
+def test_transform_constants_equal_the_oracles_in_their_own_layout():
+    """the product keeps the DCT / MDCT constants in its own layout (hx_types.h): heap-ordered twiddles of the
+    32-point DCT, and the 9-point cosine transform's rows split by the half they act on"""
+    from hmp3_amd import api
+    l = O.lib()
+    l.hxo_debug_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_longlong]
+    l.hxo_debug_table.restype = C.c_longlong
+    eo = O.OracleEncoder(O.default_control(bitrate=64))
+    eg = api.default_control(bitrate=64)
+
+    def orc(name, n):
+        a = np.zeros(n, np.float32)
+        assert l.hxo_debug_table(eo.h, name.encode(), a.ctypes.data, a.nbytes) == a.nbytes, name
+        return a.view(np.uint32)
+
+    def prod(name, n):
+        a = np.zeros(n, np.float32)
+        assert api.lib().hx_debug_host_table(C.byref(eg), name.encode(), a.ctypes.data, a.nbytes) == a.nbytes, name
+        return a.view(np.uint32)
+    tw, coef = prod("dct_tw", 32), orc("dct_coef", 31)
+    for N in (2, 4, 8, 16, 32):
+        assert np.array_equal(tw[N // 2:N], coef[32 - N:32 - N + N // 2]), N     # the oracle stores the levels largest first
+    assert np.array_equal(prod("mdct_pre18", 18), orc("m18_w", 18))
+    assert np.array_equal(prod("mdct_odd18", 9), orc("m18_w2", 9))
+    c = orc("m18_c", 36).reshape(9, 4)
+    assert np.array_equal(prod("dct9_even", 12).reshape(3, 4), c[[2, 4, 8]])
+    assert np.array_equal(prod("dct9_odd", 12).reshape(3, 4), c[[1, 5, 7]])
+    assert prod("dct9_k3", 1)[0] == c[3, 0]
+    assert np.array_equal(prod("mdct_pre6", 6), orc("m6_v", 6))
+    assert np.array_equal(prod("mdct_odd6", 3), orc("m6_v2", 3))
+    assert prod("dct3_k", 1)[0] == orc("m6_c87", 1)[0]
 
 
 def test_resolve_rejects_what_reference_rejects_and_out_of_scope():
