@@ -141,7 +141,7 @@ def _verify_worker(args):
 def verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, steps_total):
     """byte-compare the last step's output of streams `ids` with the oracle; returns (n_ok, first bad id)"""
     import multiprocessing as mp
-    F = wl["F"]
+    F = pcm.shape[1] // 1152
     host_pcm = pcm[torch.as_tensor(ids, device=pcm.device)].cpu().numpy()
     host_out = out[torch.as_tensor(ids, device=out.device)].cpu().numpy()
     host_nb = nbytes.cpu().numpy()
@@ -154,7 +154,9 @@ def verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, steps_total):
         if got == want[k]:
             ok += 1
         elif bad is None:
-            bad = int(i)
+            n = min(len(got), len(want[k]))
+            diff = next((j for j in range(n) if got[j] != want[k][j]), n)
+            bad = {"stream": int(i), "bytes": len(got), "oracle_bytes": len(want[k]), "first_difference_at": diff}
     return ok, bad
 
 

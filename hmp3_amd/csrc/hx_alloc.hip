@@ -65,7 +65,7 @@ struct alignas(16) AllocLds {
             int snr[2][NB], Noise0[2][NB], Noise[2][NB], NT[2][NB];
             int gzero[2][NB], gmin[2][NB], gsf[2][NB], sf[2][NB], active[2][NB];
             int ixmax[2][NB], ix10xmax[2][NB], up[2][NB], lo[2][NB], geval[2][NB], maskmb[2][NB];
-            float xsxx[2][NB], xsxxms[2][NB], x34max[2][NB];
+            float xsxx[2][NB], x34max[2][NB];
             float gig[2][NB], gg[2][NB];        // gain pair of the band's current evaluation step
             int lucky[6][2][13];                // big_lucky_noise: noise of candidate c of band (ch, sfb)
         };
@@ -81,7 +81,7 @@ struct alignas(16) AllocLds {
     int G[2], preemp[2], scale[2], huff_bits[2];
     int hs_table[2][4], hs_cbreg[2][3], hs_nbig[2], hs_nquads[2], hs_bits[2];
     // stream scalars (persist across frames)
-    int MNR, PoolFraction, call_count, ms_memory;
+    int MNR, PoolFraction, call_count;
     int hf_quant, hf_quant_stereo[2], gsf_hf, gsf_hf_stereo[2];
     int sf_save[2][21];
     int scfsi[2];
@@ -140,12 +140,19 @@ struct alignas(16) AllocLds {
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_POW34, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_EMIT };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_EMIT };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_JOIN() WG_BARRIER()
+
+// 16 bytes per lane from global memory straight into LDS: lane l's bytes land at lds + 16 l (the LDS base is
+// wave-uniform); completion is counted by vmcnt like any vector memory load
+__device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g, (__attribute__((address_space(3))) void *) lds, 16, 0, 0);
+}
 
 // ---------------------------------------------------------------------------------------
 // bit staging: OR an n-bit field (n <= 32) at absolute bit position pos
@@ -164,96 +171,8 @@ __device__ __forceinline__ void put_bits64(AllocLds &L, int pos, unsigned long l
     else put_bits(L, pos, (unsigned) val, n);
 }
 
-// sequential (reference-order) sum of term[ch][start .. start+n)
-// Every scalefactor band starts on an even line and has an even width (ISO Table B.8), so the
-// terms are fetched as 8-byte pairs, four pairs in flight, and added strictly in line order.
-__device__ __forceinline__ float band_sum(const float *t, int n, float acc)
-{
-    // Blocks of eight pairs, software pipelined (the next block's loads are in flight while the
-    // sixteen dependent adds of this one retire), then tails of 4 / 2 / 1 pairs.  Lanes with a
-    // narrower band simply drop out of the loops (exec mask), no per-element predicates.
-    const float2 *t2 = reinterpret_cast<const float2 *>(t);
-    const int m = n >> 1;
-    int j = 0;
-    if (m >= 8) {
-        float2 c[8], nx[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = t2[k];
-        for (j = 8; j + 8 <= m; j += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) nx[k] = t2[j + k];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { acc += c[k].x; acc += c[k].y; }
-#pragma unroll
-            for (int k = 0; k < 8; k++) c[k] = nx[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { acc += c[k].x; acc += c[k].y; }
-    }
-    if (j + 4 <= m) {
-        float2 a = t2[j], b = t2[j + 1], c = t2[j + 2], d = t2[j + 3];
-        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
-        acc += c.x; acc += c.y; acc += d.x; acc += d.y;
-        j += 4;
-    }
-    if (j + 2 <= m) {
-        float2 a = t2[j], b = t2[j + 1];
-        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
-        j += 2;
-    }
-    if (j < m) { float2 a = t2[j]; acc += a.x; acc += a.y; }
-    return acc;
-}
-// two independent sums over the same band of two term arrays (same order each), pipelined like
-// band_sum; the two add chains interleave
-__device__ __forceinline__ void band_sum2(const float *t, const float *u, int n, float *s0, float *s1)
-{
-    const float2 *t2 = reinterpret_cast<const float2 *>(t), *u2 = reinterpret_cast<const float2 *>(u);
-    const int m = n >> 1;
-    float a0 = 0.0f, a1 = 0.0f;
-    int j = 0;
-    if (m >= 8) {
-        float2 c[8], d[8], nc[8], nd[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { c[k] = t2[k]; d[k] = u2[k]; }
-        for (j = 8; j + 8 <= m; j += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) { nc[k] = t2[j + k]; nd[k] = u2[j + k]; }
-#pragma unroll
-            for (int k = 0; k < 8; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
-#pragma unroll
-            for (int k = 0; k < 8; k++) { c[k] = nc[k]; d[k] = nd[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
-    }
-    if (j + 4 <= m) {
-        float2 c[4], d[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { c[k] = t2[j + k]; d[k] = u2[j + k]; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
-        j += 4;
-    }
-    if (j + 2 <= m) {
-        float2 c0 = t2[j], c1 = t2[j + 1], d0 = u2[j], d1 = u2[j + 1];
-        a0 += c0.x; a1 += d0.x; a0 += c0.y; a1 += d0.y;
-        a0 += c1.x; a1 += d1.x; a0 += c1.y; a1 += d1.y;
-        j += 2;
-    }
-    if (j < m) { float2 c0 = t2[j], d0 = u2[j]; a0 += c0.x; a1 += d0.x; a0 += c0.y; a1 += d0.y; }
-    *s0 = a0;
-    *s1 = a1;
-}
-
 // x^(3/4): piecewise-linear mantissa fit x exponent table (reference pow34.c:132-154)
-__device__ __forceinline__ float pow34(const AllocLds &L, float x)
-{
-    unsigned u = hx_f2bits(x);
-    float m = hx_bits2f((u & 0x7FFFFFu) | (127u << 23));
-    unsigned seg = (u >> 19) & 15, e = (u >> 23) & 255;
-    return (m * L.pow34_b[seg] + L.pow34_a[seg]) * L.pow34_exp[e];
-}
+__device__ __forceinline__ float pow34(const AllocLds &L, float x) { return hx_pow34(L.pow34_a, L.pow34_b, L.pow34_exp, x); }
 
 __device__ __forceinline__ int logsubber(const AllocLds &L, int n1, int n2)
 {
@@ -437,164 +356,51 @@ __device__ void adjust_nt(AllocLds &L, const AllocPrm *p)
     SYNC();
 }
 
-// x^(3/4) and band maxima of the first nl lines of channel c
-__device__ __forceinline__ void pow34_lines(AllocLds &L, int c, int nl)
+// Start of a long-block granule (reference bitallo3.cpp:816-898 L/R, :902-1066 M/S).  The parts that do not
+// depend on the stream's carried state - magnitudes, signs, band energies, x^(3/4), band maxima, zero-gain
+// steps, masking thresholds - were computed by k_prep (hx_front.hip) and arrive in `in`; what is left here are
+// the noise targets, which follow the long-term MNR: band-parallel integer work.
+struct BandIn { float xsxx, x34max; int n0, n0ms, gzero, maskmb; };     // band lane (ch, sfb)'s share of HxBandPrep
+
+__device__ __forceinline__ BandIn band_fetch(const HxBandPrep *bp)
 {
-#pragma unroll 1
-    for (int c3 = 0; c3 < 3; c3++) {
-        if (192 * c3 >= nl) continue;
-        float v[3];
-        int bnd[3];
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int j = LANE + 64 * (3 * c3 + k3);
-            v[k3] = pow34(L, L.xr[c][j]);
-            bnd[k3] = L.band_of_line[j];
-        }
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int j = LANE + 64 * (3 * c3 + k3);
-            const bool ok = j < nl;
-            *(ok ? &L.x34[c][j] : &L.dump[LANE]) = v[k3];
-            atomicMax(reinterpret_cast<int *>(ok ? &L.x34max[c][bnd[k3]] : &L.dump[LANE]), __float_as_int(v[k3]));
-        }
-    }
+    const int ch = LANE >> 5, i = min(LANE & 31, NB - 1);
+    BandIn b;
+    b.xsxx = bp->xsxx[ch][i]; b.x34max = bp->x34max[ch][i]; b.n0 = bp->n0[ch][i]; b.n0ms = bp->n0ms[ch][i];
+    b.gzero = bp->gzero[ch][i]; b.maskmb = bp->maskmb[ch][i];
+    return b;
 }
 
-// x^(3/4) of the first nl lines, band maxima, gzero / gmin (reference bitallo3.cpp:878-896)
-__device__ void pow34_gzero(AllocLds &L, const AllocPrm *p, int nl0, int nl1, int nb0, int nb1)
+__device__ void startup_prepped(AllocLds &L, const AllocPrm *p, int ms, const BandIn &in)
 {
-    const int ch = LANE >> 5, i = LANE & 31;
-    if (i < NB) L.x34max[ch][i] = 0.0f;
-    SYNC();
-    // band maximum: x^(3/4) >= 0, so the float order equals the order of the bit patterns
-    // (the reference's vect_fmax compares them as integers too, pow34.c:156-186)
-    // Chunks of three lines per lane, all loads (line, tables) ahead of the stores; lines past
-    // nl store into the per-lane sink so the chunk stays one basic block.
-    if (nl1 > 0) HELPER_POST(HCMD_POW34, nl1);      // channel 1 on the helper wave
-    pow34_lines(L, 0, nl0);
-    if (nl1 > 0) HELPER_JOIN();
-    SYNC();
-    if (i < (ch ? nb1 : nb0)) {
-        const float m = L.x34max[ch][i];
-        int gz = max(0, hx_round((0.017716950f * hx_mblog(L.mblog, m) + (104.585000f - 100.0f + 8.0f))));
-        L.gzero[ch][i] = gz;
-        L.gmin[ch][i] = max(0, gz - GMIN_OFFSET);
+    if (ms) {
+        if (LANE == 0 && p->vbr_flag == 0 && L.call_count > 10 && (L.TargetBits - L.minTargetBits) < 100)
+            L.MNR = min(L.MNR + 50, 2050);
+        SYNC();
     }
-    SYNC();
-}
-
-// reference bitallo3.cpp:816-898
-__device__ void startup_lr(AllocLds &L, const AllocPrm *p)
-{
-    const int mnr = L.MNR + 100;
-#pragma unroll 1
-    for (int ch = 0; ch < 2; ch++) {
-        const int nl = p->nbmax3[ch];
-#pragma unroll 1
-        for (int c3 = 0; c3 < 3; c3++) {        // three lines per lane and chunk, loads first
-            if (192 * c3 >= nl) continue;
-            float x[3];
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) x[k3] = L.xr[ch][LANE + 64 * (3 * c3 + k3)];
-#pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int j = LANE + 64 * (3 * c3 + k3);
-                if (j < nl) {
-                    float xa = x[k3];
-                    unsigned char sg = 0;
-                    if (!(xa >= 0.0f)) { sg = 1; xa = -xa; }
-                    L.signx[ch][j] = sg;
-                    L.xr[ch][j] = xa;
-                    L.term[ch][j] = xa * xa;
-                }
-            }
-        }
-    }
-    SYNC();
+    const int mnr = ms ? L.MNR : L.MNR + 100;
     const int ch = LANE >> 5, i = LANE & 31;
+    const bool eband = i < (ms ? p->nsf[0] : p->nsf3[ch]);          // bands whose energy the reference forms
+    const bool band = i < (ms ? p->nsf[0] : p->nsf[ch]);
+    const int nbz = ms ? p->nsf2[ch] : p->nsf3[ch];                 // bands that get a zero-gain step
     int act = 0;
-    if (i < p->nsf3[ch]) L.xsxx[ch][i] = band_sum(&L.term[ch][L.startBand[i]], L.nBand[i], 0.0f);
-    if (i < p->nsf[ch]) {
-        int n0 = hx_mblog(L.mblog, L.xsxx[ch][i]) - L.logcbw[i], nt;
-        if (n0 < -2000) nt = n0 + 1000;
-        else {
-            act = L.nBand[i];
-            nt = drop_guard(n0, L.maskmb[ch][i] - L.logcbw[i] - mnr + L.taper[i]);
-        }
-        L.Noise0[ch][i] = n0;
-        L.NT[ch][i] = nt;
-        L.snr[ch][i] = n0 - nt;
-    }
-    act = hx_wave_sum(act);
-    if (LANE == 0) L.activeBands = act;
-    SYNC();
-    adjust_nt(L, p);
-    pow34_gzero(L, p, p->nbmax3[0], p->nbmax3[1], p->nsf3[0], p->nsf3[1]);
-}
-
-// reference bitallo3.cpp:902-1066
-__device__ void startup_ms(AllocLds &L, const AllocPrm *p)
-{
-    if (LANE == 0 && p->vbr_flag == 0 && L.call_count > 10 && (L.TargetBits - L.minTargetBits) < 100)
-        L.MNR = min(L.MNR + 50, 2050);
-    SYNC();
-    const int mnr = L.MNR;
-    PROF_T0();
-    const int nl = p->hf_flag ? L.startBand[22] : p->nbmax[0];     // lines that get the M/S butterfly
-    // one pass over the lines: L/R energy terms, M/S butterfly (reference l3math.c:905-930, no
-    // 1/sqrt(2)), M/S energy terms (kept in the x34 array, which is not live yet)
-#pragma unroll 1
-    for (int c3 = 0; c3 < 3; c3++) {            // three lines per lane and chunk, loads first
-        if (192 * c3 >= nl) continue;
-        float lv[3], rv[3];
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) { lv[k3] = L.xr[0][LANE + 64 * (3 * c3 + k3)]; rv[k3] = L.xr[1][LANE + 64 * (3 * c3 + k3)]; }
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int j = LANE + 64 * (3 * c3 + k3);
-            if (j < nl) {
-                const float l = lv[k3], r = rv[k3];
-                L.term[0][j] = l * l;
-                L.term[1][j] = r * r;
-                float x0 = (l + r), x1 = (l - r);
-                unsigned char s0 = 0, s1 = 0;
-                if (x0 < 0.0f) { s0 = 1; x0 = -x0; }
-                if (x1 < 0.0f) { s1 = 1; x1 = -x1; }
-                L.signx[0][j] = s0; L.signx[1][j] = s1;
-                L.xr[0][j] = x0; L.xr[1][j] = x1;
-                L.x34[0][j] = x0 * x0;
-                L.x34[1][j] = x1 * x1;
-            }
-        }
-    }
-    SYNC();
-    PROF_ACC(32);
-    const int ch = LANE >> 5, i = LANE & 31;
-    const bool band = i < p->nsf[0];
+    if (i < NB) L.x34max[ch][i] = in.x34max;
+    if (eband) L.xsxx[ch][i] = in.xsxx;
     if (band) {
-        float e0, e1;
-        band_sum2(&L.term[ch][L.startBand[i]], &L.x34[ch][L.startBand[i]], L.nBand[i], &e0, &e1);
-        L.xsxx[ch][i] = e0;
-        L.xsxxms[ch][i] = e1;
-    }
-    SYNC();
-    PROF_ACC(33);
-    int act = 0;
-    if (band) {     // lane (ch, i): left (ch 0) / right (ch 1) noise target
-        int cbw = L.logcbw[i];
-        int n0 = hx_mblog(L.mblog, L.xsxx[ch][i]) - cbw, nt;
-        if (n0 < -2000) nt = 10000;
-        else { nt = drop_guard(n0, (L.maskmb[ch][i] - cbw) - mnr + L.taper[i]); act = L.nBand[i]; }
+        const int cbw = L.logcbw[i], n0 = in.n0;
+        int nt;
+        if (n0 < -2000) nt = ms ? 10000 : n0 + 1000;
+        else { act = L.nBand[i]; nt = drop_guard(n0, (in.maskmb - cbw) - mnr + L.taper[i]); }
         L.NT[ch][i] = nt;
         L.snr[ch][i] = n0 - nt;
-        L.Noise0[ch][i] = hx_mblog(L.mblog, L.xsxxms[ch][i]) - cbw;
+        L.Noise0[ch][i] = ms ? in.n0ms : n0;
     }
+    if (i < nbz) { L.gzero[ch][i] = in.gzero; L.gmin[ch][i] = max(0, in.gzero - GMIN_OFFSET); }
     act = hx_wave_sum(act);
     if (LANE == 0) L.activeBands = act;
     SYNC();
     adjust_nt(L, p);
-    if (LANE < p->nsf[0]) {
+    if (ms && LANE < p->nsf[0]) {       // targets of M and S from those of L and R (bitallo3.cpp:1014-1062)
         int b = LANE;
         int NTL = L.NT[0][b], NTR = L.NT[1][b], Nsum = L.Noise0[0][b], Ndiff = L.Noise0[1][b];
         int xNT = min(NTL, NTR) + 300, nt0, nt1;
@@ -606,9 +412,6 @@ __device__ void startup_ms(AllocLds &L, const AllocPrm *p)
         L.snr[1][b] = Ndiff - nt1;
     }
     SYNC();
-    PROF_ACC(34);
-    pow34_gzero(L, p, p->nbmax2[0], p->nbmax2[1], p->nsf2[0], p->nsf2[1]);
-    PROF_ACC(35);
 }
 
 // reference bitallo3.cpp:1130-1160

@@ -24,12 +24,10 @@ __global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *e
 __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                        float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
 __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf, int nchan);
-struct AllocArgs {
-    HxStream *st; const HxParams *prm; const HxGlobalTabs *gt;
-    const float *xr; const float *etab, *thr; const int *msbase; const unsigned char *bt; const unsigned char *btprev;
-    unsigned char *out; int *out_bytes; HxFrameDebug *dbg; long long out_stride; int NG, S; int *status; unsigned long long *prof;
-    unsigned char *packet; long long packet_stride; int *packet_bytes; int *frame_stats; int *done_counter;
-};
+__global__ void k_msscan(HxStream *st, const HxParams *prm, const int *msbase, const unsigned char *bt, unsigned char *msflag, int *msdec,
+                         const float *thr, float *thrprev, int NG, int lsf);
+__global__ void k_prep(float *xr, float *x34o, unsigned char *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
+                       const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
@@ -56,6 +54,11 @@ struct hx_batch {
     HxGlobalTabs *d_gt = nullptr;
     HxStream *d_st = nullptr;
     float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
+    // k_msscan / k_prep -> k_alloc: x^(3/4), signs, band start values, stereo decision, pre-echo memory at call start
+    float *d_x34 = nullptr, *d_thrprev = nullptr, *d_xrdbg = nullptr;
+    unsigned char *d_sgn = nullptr, *d_msflag = nullptr;
+    HxBandPrep *d_band = nullptr;
+    int *d_msdec = nullptr;
     int *frame_stats = nullptr;         // caller's per-frame counters (device), optional
     unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
@@ -77,9 +80,10 @@ struct hx_batch {
     // hx_batch_submit_*: the front-end kernels of call n+1 run (low-priority stream) while k_alloc of
     // call n (high-priority stream) works through its slowest streams; a second set of the buffers
     // that hand granules from the front end to k_alloc makes that safe.
-    float *d_xr2 = nullptr, *d_etab2 = nullptr, *d_thr2 = nullptr;
-    int *d_msbase2 = nullptr;
-    unsigned char *d_bt2 = nullptr, *d_btprev2 = nullptr;
+    float *d_xr2 = nullptr, *d_etab2 = nullptr, *d_thr2 = nullptr, *d_x342 = nullptr, *d_thrprev2 = nullptr;
+    int *d_msbase2 = nullptr, *d_msdec2 = nullptr;
+    unsigned char *d_bt2 = nullptr, *d_btprev2 = nullptr, *d_sgn2 = nullptr, *d_msflag2 = nullptr;
+    HxBandPrep *d_band2 = nullptr;
     hipStream_t s_front = nullptr, s_alloc = nullptr;
     hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};
     long long nsubmit = 0;
@@ -118,7 +122,9 @@ extern "C" void hx_batch_destroy(hx_batch *b)
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
                     b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
-                    b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done};
+                    b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done,
+                    b->d_x34, b->d_thrprev, b->d_xrdbg, b->d_sgn, b->d_msflag, b->d_band, b->d_msdec,
+                    b->d_x342, b->d_thrprev2, b->d_sgn2, b->d_msflag2, b->d_band2, b->d_msdec2};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 2; i++) {
         if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]);
@@ -190,6 +196,12 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_xr, sizeof(float) * S * NG * 1152);
     ALLOC(b->d_etab, sizeof(float) * S * NG * 128);
     ALLOC(b->d_thr, sizeof(float) * S * NG * 128);
+    ALLOC(b->d_x34, sizeof(float) * S * NG * 1152);
+    ALLOC(b->d_sgn, S * NG * 1152);
+    ALLOC(b->d_band, sizeof(HxBandPrep) * S * NG);
+    ALLOC(b->d_msflag, S * NG);
+    ALLOC(b->d_msdec, sizeof(int) * S * NG);
+    ALLOC(b->d_thrprev, sizeof(float) * S * 128);
     ALLOC(b->d_eng, sizeof(int) * S * 2 * NG * 9);
     ALLOC(b->d_msbase, sizeof(int) * S * NG);
     ALLOC(b->d_flg, S * NG);
@@ -316,6 +328,7 @@ extern "C" void hx_batch_debug_enable(hx_batch *b, int on)
     if (on && !b->d_dbg) {
         hipSetDevice(b->device);
         hipMalloc((void **) &b->d_dbg, sizeof(HxFrameDebug) * (size_t) b->S * b->maxF);
+        hipMalloc((void **) &b->d_xrdbg, sizeof(float) * (size_t) b->S * 2 * b->maxF * 1152);
         hipMalloc((void **) &b->d_dbgmetric, sizeof(int) * (size_t) b->S * 2 * b->maxF * 2);
         hipMalloc((void **) &b->d_prof, sizeof(unsigned long long) * (size_t) b->S * 64);
         hipMemset(b->d_prof, 0, sizeof(unsigned long long) * (size_t) b->S * 64);
@@ -342,6 +355,12 @@ static int pipe_init(hx_batch *b)
     HIPCHK(hipMalloc((void **) &b->d_msbase2, sizeof(int) * S * NG));
     HIPCHK(hipMalloc((void **) &b->d_bt2, S * NG));
     HIPCHK(hipMalloc((void **) &b->d_btprev2, S));
+    HIPCHK(hipMalloc((void **) &b->d_x342, sizeof(float) * S * NG * 1152));
+    HIPCHK(hipMalloc((void **) &b->d_sgn2, S * NG * 1152));
+    HIPCHK(hipMalloc((void **) &b->d_band2, sizeof(HxBandPrep) * S * NG));
+    HIPCHK(hipMalloc((void **) &b->d_msflag2, S * NG));
+    HIPCHK(hipMalloc((void **) &b->d_msdec2, sizeof(int) * S * NG));
+    HIPCHK(hipMalloc((void **) &b->d_thrprev2, sizeof(float) * S * 128));
     return 0;
 }
 
@@ -387,6 +406,10 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     float *const x_xr = set ? b->d_xr2 : b->d_xr, *const x_etab = set ? b->d_etab2 : b->d_etab, *const x_thr = set ? b->d_thr2 : b->d_thr;
     int *const x_msbase = set ? b->d_msbase2 : b->d_msbase;
     unsigned char *const x_bt = set ? b->d_bt2 : b->d_bt, *const x_btprev = set ? b->d_btprev2 : b->d_btprev;
+    float *const x_x34 = set ? b->d_x342 : b->d_x34, *const x_thrprev = set ? b->d_thrprev2 : b->d_thrprev;
+    unsigned char *const x_sgn = set ? b->d_sgn2 : b->d_sgn, *const x_msflag = set ? b->d_msflag2 : b->d_msflag;
+    HxBandPrep *const x_band = set ? b->d_band2 : b->d_band;
+    int *const x_msdec = set ? b->d_msdec2 : b->d_msdec;
     const int S = b->S, NG = 2 * nframes;
     const long long nsamp = 1152LL * nframes;
     // The subband carry sits in slots NG_prev..NG_prev+2 only if the previous call used another
@@ -404,6 +427,12 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     LAUNCH(k_blocktype, dim3((S + 63) / 64), dim3(64), q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
     LAUNCH(k_spec, dim3((unsigned) ((long long) S * NG)), dim3(64), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
            x_etab, x_thr, x_msbase, NG, SG);
+    // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
+    // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
+    if (b->debug && b->d_xrdbg) HIPCHK(hipMemcpyAsync(b->d_xrdbg, x_xr, sizeof(float) * (size_t) S * NG * 1152, hipMemcpyDeviceToDevice, q));
+    LAUNCH(k_msscan, dim3(S), dim3(64), q, b->d_st, b->d_prm, x_msbase, x_bt, x_msflag, x_msdec, x_thr, x_thrprev, NG, b->lsf);
+    LAUNCH(k_prep, dim3((unsigned) ((long long) S * NG)), dim3(64), q, x_xr, x_x34, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
+           x_etab, x_thr, x_thrprev, NG);
     // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
     LAUNCH(k_carry, dim3(S * 2), dim3(256), q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
     if (pipelined) {
@@ -416,6 +445,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
     a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
     a.done_counter = b->d_done;
+    a.x34 = x_x34; a.sgn = x_sgn; a.band = x_band; a.msflag = x_msflag; a.msdec = x_msdec; a.thrprev = x_thrprev;
     b->alloc_launches++;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
@@ -689,7 +719,11 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     long long n = 0;
     std::string k(name);
     if (k == "sb") { src = b->d_sb; n = sizeof(float) * S * 2 * (2LL * b->maxF + 3) * 576; }
-    else if (k == "xr") { src = b->d_xr; n = sizeof(float) * S * NG * 1152; }
+    else if (k == "xr") { src = b->d_xrdbg ? b->d_xrdbg : b->d_xr; n = sizeof(float) * S * NG * 1152; }     // the spectrum before k_prep (debug tap)
+    else if (k == "xmag") { src = b->d_xr; n = sizeof(float) * S * NG * 1152; }
+    else if (k == "x34") { src = b->d_x34; n = sizeof(float) * S * NG * 1152; }
+    else if (k == "band") { src = b->d_band; n = sizeof(HxBandPrep) * S * NG; }
+    else if (k == "msflag") { src = b->d_msflag; n = S * NG; }
     else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }
     else if (k == "thr") { src = b->d_thr; n = sizeof(float) * S * NG * 128; }
     else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }

@@ -86,3 +86,95 @@ __device__ __forceinline__ int hx_half_or(int v)
     const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
     return (threadIdx.x & 32) ? hi : lo;
 }
+
+// x^(3/4): piecewise-linear mantissa fit x exponent table (reference pow34.c:132-154)
+__device__ __forceinline__ float hx_pow34(const float *a, const float *b, const float *ex, float x)
+{
+    unsigned u = hx_f2bits(x);
+    float m = hx_bits2f((u & 0x7FFFFFu) | (127u << 23));
+    unsigned seg = (u >> 19) & 15, e = (u >> 23) & 255;
+    return (m * b[seg] + a[seg]) * ex[e];
+}
+
+// sequential (reference-order) sum of term[ch][start .. start+n)
+// Every scalefactor band starts on an even line and has an even width (ISO Table B.8), so the
+// terms are fetched as 8-byte pairs, four pairs in flight, and added strictly in line order.
+__device__ __forceinline__ float band_sum(const float *t, int n, float acc)
+{
+    // Blocks of eight pairs, software pipelined (the next block's loads are in flight while the
+    // sixteen dependent adds of this one retire), then tails of 4 / 2 / 1 pairs.  Lanes with a
+    // narrower band simply drop out of the loops (exec mask), no per-element predicates.
+    const float2 *t2 = reinterpret_cast<const float2 *>(t);
+    const int m = n >> 1;
+    int j = 0;
+    if (m >= 8) {
+        float2 c[8], nx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = t2[k];
+        for (j = 8; j + 8 <= m; j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) nx[k] = t2[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { acc += c[k].x; acc += c[k].y; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = nx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc += c[k].x; acc += c[k].y; }
+    }
+    if (j + 4 <= m) {
+        float2 a = t2[j], b = t2[j + 1], c = t2[j + 2], d = t2[j + 3];
+        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
+        acc += c.x; acc += c.y; acc += d.x; acc += d.y;
+        j += 4;
+    }
+    if (j + 2 <= m) {
+        float2 a = t2[j], b = t2[j + 1];
+        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
+        j += 2;
+    }
+    if (j < m) { float2 a = t2[j]; acc += a.x; acc += a.y; }
+    return acc;
+}
+// two independent sums over the same band of two term arrays (same order each), pipelined like
+// band_sum; the two add chains interleave
+__device__ __forceinline__ void band_sum2(const float *t, const float *u, int n, float *s0, float *s1)
+{
+    const float2 *t2 = reinterpret_cast<const float2 *>(t), *u2 = reinterpret_cast<const float2 *>(u);
+    const int m = n >> 1;
+    float a0 = 0.0f, a1 = 0.0f;
+    int j = 0;
+    if (m >= 8) {
+        float2 c[8], d[8], nc[8], nd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { c[k] = t2[k]; d[k] = u2[k]; }
+        for (j = 8; j + 8 <= m; j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { nc[k] = t2[j + k]; nd[k] = u2[j + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { c[k] = nc[k]; d[k] = nd[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
+    }
+    if (j + 4 <= m) {
+        float2 c[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c[k] = t2[j + k]; d[k] = u2[j + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a0 += c[k].x; a1 += d[k].x; a0 += c[k].y; a1 += d[k].y; }
+        j += 4;
+    }
+    if (j + 2 <= m) {
+        float2 c0 = t2[j], c1 = t2[j + 1], d0 = u2[j], d1 = u2[j + 1];
+        a0 += c0.x; a1 += d0.x; a0 += c0.y; a1 += d0.y;
+        a0 += c1.x; a1 += d1.x; a0 += c1.y; a1 += d1.y;
+        j += 2;
+    }
+    if (j < m) { float2 c0 = t2[j], d0 = u2[j]; a0 += c0.x; a1 += d0.x; a0 += c0.y; a1 += d0.y; }
+    *s0 = a0;
+    *s1 = a1;
+}
+

@@ -586,6 +586,215 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
     msmetric_unit(xl, xl + 576, p, gt, msbase + sg, btype == 2);
 }
 
+// K5a: the frame's stereo decision (joint-stereo streams), serial per stream over its granules, and the hand-over
+// of the pre-echo memory between calls.  The L/R-vs-M/S metric of a granule gets a +-5000 hysteresis from the
+// previous long granule; a short granule takes none and clears it (reference bitallo3.cpp:693-698,743-751); an
+// MPEG-1 frame is coded M/S when its two granules' values sum to >= 0 (mp3enc.cpp:1538-1546), an MPEG-2 frame by
+// its one granule.  Depends on front-end data only, so it runs here and not in the per-stream allocator walk.
+__global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const HxParams *__restrict__ prm, const int *__restrict__ msbase,
+                                               const unsigned char *__restrict__ bt, unsigned char *__restrict__ msflag, int *__restrict__ msdec,
+                                               const float *__restrict__ thr, float *__restrict__ thrprev, int NG, int lsf)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    HxStream *ss = st + s;
+    const long long g0 = (long long) s * NG;
+    if (lane == 0) {
+        const int on = prm[ss->cls].ms_flag;
+        int mem = ss->ms_memory;
+        for (int g = 0; g < NG; g += 2) {
+            int m1 = 0, m2 = 0;
+            if (on) {
+                m1 = msbase[g0 + g];
+                if (bt[g0 + g] == 2) mem = 0; else { m1 += mem; mem = (m1 > 0) ? 5000 : -5000; }
+                m2 = msbase[g0 + g + 1];
+                if (bt[g0 + g + 1] == 2) mem = 0; else { m2 += mem; mem = (m2 > 0) ? 5000 : -5000; }
+            }
+            msdec[g0 + g] = m1;
+            msdec[g0 + g + 1] = m2;
+            msflag[g0 + g] = (unsigned char) (on && (lsf ? m1 : m1 + m2) >= 0);
+            msflag[g0 + g + 1] = (unsigned char) (on && (lsf ? m2 : m1 + m2) >= 0);
+        }
+        ss->ms_memory = mem;
+    }
+    // pre-echo memory ("ecsave", reference spdsmr.c:112-117,283-298): this call's first granule is clamped against
+    // the stream's carried values, which then become the doubled unclamped thresholds of this call's last granule
+    // (long), or its doubled window-2 sums in entries 0..11 (short)
+    const float *last = thr + (g0 + NG - 1) * 128;
+    const int lastbt = bt[g0 + NG - 1];
+    for (int i = lane; i < 128; i += 64) {
+        const float old = (&ss->thr_prev[0][0])[i];
+        thrprev[(long long) s * 128 + i] = old;
+        float nw = old;
+        if (lastbt != 2) nw = 2.0f * last[i];
+        else if ((i & 63) < 12) nw = 2.0f * last[(i & 64) + 24 + (i & 63)];
+        (&ss->thr_prev[0][0])[i] = nw;
+    }
+}
+
+// K5b: everything the allocator does at the start of a long-block granule that does not depend on its carried
+// state, one wavefront per (stream, granule): magnitudes and signs of the lines in the representation the frame
+// is coded in (L / R, or M = L + R, S = L - R: reference l3math.c:449-470,905-930), band energies in line order
+// (bitallo3.cpp:816-864,902-985), x^(3/4) of every line with the band maxima and the zero-gain steps
+// (:878-896, pow34.c:132-186), and the masking thresholds after pre-echo control (spdsmr.c:275-318).  The
+// magnitudes replace the spectrum in place; short-block granules are left as they are (their allocator starts
+// from the raw spectrum).
+__global__ __launch_bounds__(64) void k_prep(float *__restrict__ xr, float *__restrict__ x34o, unsigned char *__restrict__ sgn,
+                                             HxBandPrep *__restrict__ band, const HxStream *__restrict__ st,
+                                             const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
+                                             const unsigned char *__restrict__ bt, const unsigned char *__restrict__ msflag,
+                                             const float *__restrict__ etab, const float *__restrict__ thr,
+                                             const float *__restrict__ thrprev, int NG)
+{
+    __shared__ __attribute__((aligned(16))) float xa[2][576];   // magnitudes
+    __shared__ __attribute__((aligned(16))) float ta[2][576];   // squares of L, R
+    __shared__ __attribute__((aligned(16))) float tb[2][576];   // squares of M, S; then x^(3/4)
+    __shared__ __attribute__((aligned(16))) unsigned char sg[2][576];
+    __shared__ int xmax[2][22];
+    const int lane = threadIdx.x;
+    const long long unit = blockIdx.x;          // (s, g)
+    const int g = (int) (unit % NG), s = (int) (unit / NG);
+    const int btype = bt[unit];
+    if (btype == 2) return;
+    const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
+    const int ms = msflag[unit];
+    const int two = p->nchan == 2;
+    const int nsf0 = p->nsf[0], nsf1 = two ? p->nsf[1] : 0;
+    // lines that get magnitudes / x^(3/4), bands that get energies / maxima (reference: nbmax, nbmax2 / nbmax3 ...)
+    const int nl_mag0 = ms ? (p->hf_flag ? p->startBand_l[22] : p->nbmax[0]) : p->nbmax3[0];
+    const int nl_mag1 = ms ? nl_mag0 : (two ? p->nbmax3[1] : 0);
+    const int nl_p0 = ms ? p->nbmax2[0] : p->nbmax3[0], nl_p1 = two ? (ms ? p->nbmax2[1] : p->nbmax3[1]) : 0;
+    const int nb_e0 = ms ? nsf0 : p->nsf3[0], nb_e1 = ms ? nsf0 : (two ? p->nsf3[1] : 0);
+    const int nb_z0 = ms ? p->nsf2[0] : p->nsf3[0], nb_z1 = two ? (ms ? p->nsf2[1] : p->nsf3[1]) : 0;
+    float *x = xr + unit * 1152;
+    if (lane < 44) xmax[lane / 22][lane % 22] = 0;
+    {   // lines: 16 bytes per lane and load, both channels of a line in the same lane
+        float4 lv[3], rv[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = min(lane + 64 * k, 143);
+            lv[k] = reinterpret_cast<const float4 *>(x)[e];
+            rv[k] = reinterpret_cast<const float4 *>(x + 576)[e];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = lane + 64 * k;
+            if (e >= 144) continue;
+            const float l4[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w}, r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+            float a0[4], a1[4], t0[4], t1[4], u0[4], u1[4];
+            unsigned s0 = 0, s1 = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int j = 4 * e + c;
+                const float l = l4[c], r = r4[c];
+                a0[c] = l; a1[c] = r; t0[c] = t1[c] = u0[c] = u1[c] = 0.0f;
+                if (ms) {
+                    if (j < nl_mag0) {
+                        t0[c] = l * l;
+                        t1[c] = r * r;
+                        float m = (l + r), d = (l - r);
+                        if (m < 0.0f) { s0 |= 1u << (8 * c); m = -m; }
+                        if (d < 0.0f) { s1 |= 1u << (8 * c); d = -d; }
+                        a0[c] = m; a1[c] = d;
+                        u0[c] = m * m;
+                        u1[c] = d * d;
+                    }
+                } else {
+                    if (j < nl_mag0) { float v = l; if (!(v >= 0.0f)) { s0 |= 1u << (8 * c); v = -v; } a0[c] = v; t0[c] = v * v; }
+                    if (j < nl_mag1) { float v = r; if (!(v >= 0.0f)) { s1 |= 1u << (8 * c); v = -v; } a1[c] = v; t1[c] = v * v; }
+                }
+            }
+            reinterpret_cast<float4 *>(xa[0])[e] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+            reinterpret_cast<float4 *>(xa[1])[e] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            reinterpret_cast<float4 *>(ta[0])[e] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+            reinterpret_cast<float4 *>(ta[1])[e] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+            reinterpret_cast<float4 *>(tb[0])[e] = make_float4(u0[0], u0[1], u0[2], u0[3]);
+            reinterpret_cast<float4 *>(tb[1])[e] = make_float4(u1[0], u1[1], u1[2], u1[3]);
+            reinterpret_cast<unsigned *>(sg[0])[e] = s0;
+            reinterpret_cast<unsigned *>(sg[1])[e] = s1;
+        }
+    }
+    __syncthreads();
+    // band energies: lane (ch, sfb) adds its band's squares in line order
+    const int ch = lane >> 5, i = lane & 31;
+    const int cbw = (i < 22) ? p->look_log_cbwmb[i] : 0;
+    float e_lr = 0.0f;
+    int n0 = 0, n0ms = 0;
+    if (i < (ch ? nb_e1 : nb_e0)) {
+        const int b0 = p->startBand_l[i], n = p->nBand_l[i];
+        if (ms) {
+            float e_ms;
+            band_sum2(&ta[ch][b0], &tb[ch][b0], n, &e_lr, &e_ms);
+            n0ms = hx_mblog(gt->mblog, e_ms) - cbw;
+        } else e_lr = band_sum(&ta[ch][b0], n, 0.0f);
+        n0 = hx_mblog(gt->mblog, e_lr) - cbw;
+    }
+    __syncthreads();        // tb is reused for x^(3/4)
+    {   // x^(3/4) of the coded magnitudes and the band maxima (bit patterns of non-negative floats order like integers)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = lane + 64 * k;
+            if (e >= 144) continue;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                const float4 v = reinterpret_cast<const float4 *>(xa[c2])[e];
+                const float m4[4] = {v.x, v.y, v.z, v.w};
+                float q[4];
+                const int nl = c2 ? nl_p1 : nl_p0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int j = 4 * e + c;
+                    q[c] = 0.0f;
+                    if (j < nl) {
+                        q[c] = hx_pow34(gt->pow34_a, gt->pow34_b, gt->pow34_exp, m4[c]);
+                        atomicMax(&xmax[c2][p->band_of_line[j]], __float_as_int(q[c]));
+                    }
+                }
+                reinterpret_cast<float4 *>(tb[c2])[e] = make_float4(q[0], q[1], q[2], q[3]);
+            }
+        }
+    }
+    __syncthreads();
+    int gz = 0;
+    float xm = 0.0f;
+    if (i < 22) xm = __int_as_float(xmax[ch][i]);
+    if (i < (ch ? nb_z1 : nb_z0)) gz = max(0, hx_round((0.017716950f * hx_mblog(gt->mblog, xm) + (104.585000f - 100.0f + 8.0f))));
+    // masking threshold of the band: the two partitions' thresholds, each clamped against twice the previous
+    // granule's unless this is a stop block, weighted by the partitions' energies
+    int mmb = 0;
+    if (i < 21) {
+        const float2 th = reinterpret_cast<const float2 *>(thr + unit * 128 + ch * 64)[i];
+        const float2 en = reinterpret_cast<const float2 *>(etab + unit * 128 + ch * 64)[i];
+        const float2 pv = reinterpret_cast<const float2 *>((g == 0 ? thrprev + (long long) s * 128 : thr + (unit - 1) * 128) + ch * 64)[i];
+        float s1 = th.x, s2 = th.y;
+        const float t1 = (g == 0) ? pv.x : 2.0f * pv.x, t2 = (g == 0) ? pv.y : 2.0f * pv.y;
+        if (btype != 3) {
+            if (s1 > t1) { const float f = 0.1f * s1; s1 = t1; if (s1 < f) s1 = f; }
+            if (s2 > t2) { const float f = 0.1f * s2; s2 = t2; if (s2 < f) s2 = f; }
+        }
+        float emax = en.x;
+        if (emax < en.y) emax = en.y;
+        mmb = hx_mblog(gt->mblog, (en.x * s1 + en.y * s2) / emax);
+    }
+    HxBandPrep *bp = band + unit;
+    if (i < 22) {
+        bp->xsxx[ch][i] = e_lr; bp->x34max[ch][i] = xm; bp->n0[ch][i] = n0; bp->n0ms[ch][i] = n0ms;
+        bp->gzero[ch][i] = gz; bp->maskmb[ch][i] = mmb;
+    }
+    {   // magnitudes over the spectrum, x^(3/4) and signs to their buffers: 16 bytes per lane and store
+        float4 *dx = reinterpret_cast<float4 *>(x), *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);
+        const float4 *sx = reinterpret_cast<const float4 *>(&xa[0][0]), *sq = reinterpret_cast<const float4 *>(&tb[0][0]);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = lane + 64 * k;
+            if (e < 288) { dx[e] = sx[e]; dq[e] = sq[e]; }
+        }
+        uint4 *ds = reinterpret_cast<uint4 *>(sgn + unit * 1152);
+        const uint4 *ss4 = reinterpret_cast<const uint4 *>(&sg[0][0]);
+        ds[lane] = ss4[lane];
+        if (lane < 8) ds[64 + lane] = ss4[64 + lane];
+    }
+}
+
 // After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
 // last 480 input samples into the stream state.
 __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const int16_t *__restrict__ pcm,

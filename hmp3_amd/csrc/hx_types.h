@@ -120,6 +120,18 @@ struct HxStream {
     unsigned char main_buf[HX_MAINBUF];
 };
 
+// What the allocator needs at the start of a long-block granule and that does not depend on its carried state:
+// written by k_prep per (stream, granule), read by k_alloc.  Energies are those of the input channels (L / R);
+// x34max / gzero refer to the representation the frame is coded in (L / R, or M / S in a joint-stereo frame).
+struct alignas(16) HxBandPrep {
+    float xsxx[2][22];          // band energies of L and R
+    float x34max[2][22];        // largest |x|^(3/4) of the band
+    int n0[2][22];              // band energy per line in mB: L, R
+    int n0ms[2][22];            // the same of M, S (joint-stereo frames only)
+    int gzero[2][22];           // gain step at which the whole band quantises to zero
+    int maskmb[2][22];          // masking threshold in mB after pre-echo control
+};
+
 // Optional per-frame debug taps written by the allocator kernel (tests only).
 struct HxFrameDebug {
     int ms, ms_metric[2], byte_pool, MNR_after;
@@ -129,3 +141,35 @@ struct HxFrameDebug {
     int scfsi[2];
     int main_bytes;             // bytes of main data produced by this frame (before padding)
 };
+
+// Arguments of the allocator kernels (k_alloc / k_alloc_lsf), filled by the host runtime.
+struct AllocArgs {
+    HxStream *st;
+    const HxParams *prm;
+    const HxGlobalTabs *gt;
+    const float *xr;            // [S][NG][2][576]
+    const float *etab, *thr;    // [S][NG][2][64]
+    const int *msbase;          // [S][NG]
+    const unsigned char *bt;    // [S][NG]
+    const unsigned char *btprev;    // [S] block type of the granule before this call
+    unsigned char *out;         // [S][out_stride]
+    int *out_bytes;             // [S]
+    HxFrameDebug *dbg;          // [S][F] or null
+    long long out_stride;
+    int NG, S;
+    int *status;
+    unsigned long long *prof;
+    unsigned char *packet;      // optional [S][F][packet_stride]: each frame as a self-contained packet
+    long long packet_stride;
+    int *packet_bytes;          // [S][F]
+    int *frame_stats;           // optional [S][F][2]: frames / bytes emitted by the stream after each input frame
+    int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter)
+    // from k_msscan / k_prep (hx_front.hip); xr holds the coded magnitudes for long-block granules
+    const float *x34;           // [S][NG][2][576] x^(3/4) of the magnitudes (long-block granules)
+    const unsigned char *sgn;   // [S][NG][2][576] sign of each line
+    const HxBandPrep *band;     // [S][NG]
+    const unsigned char *msflag;    // [S][NG] 1 = the granule's frame is coded M/S
+    const int *msdec;           // [S][NG] the stereo metric after hysteresis (debug taps)
+    const float *thrprev;       // [S][2][64] pre-echo memory the call started with
+};
+
