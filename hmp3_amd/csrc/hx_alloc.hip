@@ -52,7 +52,6 @@ struct alignas(16) AllocLds {
     int mblog[256];
     float pow34_exp[256], pow34_a[16], pow34_b[16], quant_off[32];
     int logsub[84];
-    unsigned short huff_code[1408];
     unsigned char huff_len[1408];
     unsigned char sband_of_line[192];
     int nBand_s[16], startBand_s[16], logcbw_s[16];
@@ -89,9 +88,7 @@ struct alignas(16) AllocLds {
     int nchan, block_type, maxBits, maxTargetBits, minTargetBits, PoolBits, TargetBits, deltaMNR, activeBands;
     int tmp[8];
     int tmpn[2][NB];
-    // bit staging for one frame's main data (MSB-first 32-bit words)
-    unsigned int bitw[640];
-    unsigned int sidew[10];
+    unsigned int sidew[10];             // bit staging of the side information
     HxGr gr[2][2];
     int sfout[2][2][NB];
     int sfs[2][3][12];                  // short-block scalefactors of the current granule
@@ -140,7 +137,7 @@ struct alignas(16) AllocLds {
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_EMIT };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \
@@ -152,23 +149,6 @@ enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_ISF2, HCMD_LU
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g, (__attribute__((address_space(3))) void *) lds, 16, 0, 0);
-}
-
-// ---------------------------------------------------------------------------------------
-// bit staging: OR an n-bit field (n <= 32) at absolute bit position pos
-__device__ __forceinline__ void put_bits(AllocLds &L, int pos, unsigned val, int n)
-{
-    if (n <= 0) return;
-    int w = pos >> 5, o = pos & 31;
-    unsigned long long v = ((unsigned long long) val) << (64 - n - o);  // field left-aligned in 64 bits at offset o
-    unsigned hi = (unsigned) (v >> 32), lo = (unsigned) v;
-    if (hi) atomicOr(&L.bitw[w], hi);
-    if (lo) atomicOr(&L.bitw[w + 1], lo);
-}
-__device__ __forceinline__ void put_bits64(AllocLds &L, int pos, unsigned long long val, int n)
-{
-    if (n > 32) { put_bits(L, pos, (unsigned) (val >> 32), n - 32); put_bits(L, pos + n - 32, (unsigned) val, 32); }
-    else put_bits(L, pos, (unsigned) val, n);
 }
 
 // x^(3/4): piecewise-linear mantissa fit x exponent table (reference pow34.c:132-154)

@@ -27,7 +27,11 @@ __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long n
 __global__ void k_msscan(HxStream *st, const HxParams *prm, const int *msbase, const unsigned char *bt, unsigned char *msflag, int *msdec,
                          const float *thr, float *thrprev, int NG, int lsf);
 __global__ void k_prep(float *xr, float *x34o, unsigned char *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
-                       const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG);
+                       const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG, long long nunits);
+__global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned char *sgn, const HxSegOut *seg,
+                       const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
+                       int frames_per_stream, int NG, int lsf);
+__global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
@@ -59,6 +63,11 @@ struct hx_batch {
     unsigned char *d_sgn = nullptr, *d_msflag = nullptr;
     HxBandPrep *d_band = nullptr;
     int *d_msdec = nullptr;
+    // k_alloc -> k_pack: quantised lines, segment and frame records, slot lists
+    short *d_ixq = nullptr;
+    HxSegOut *d_seg = nullptr;
+    HxFrameOut *d_frm = nullptr;
+    HxSlot *d_slots = nullptr;
     int *frame_stats = nullptr;         // caller's per-frame counters (device), optional
     unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
@@ -124,7 +133,8 @@ extern "C" void hx_batch_destroy(hx_batch *b)
                     b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
                     b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done,
                     b->d_x34, b->d_thrprev, b->d_xrdbg, b->d_sgn, b->d_msflag, b->d_band, b->d_msdec,
-                    b->d_x342, b->d_thrprev2, b->d_sgn2, b->d_msflag2, b->d_band2, b->d_msdec2};
+                    b->d_x342, b->d_thrprev2, b->d_sgn2, b->d_msflag2, b->d_band2, b->d_msdec2,
+                    b->d_ixq, b->d_seg, b->d_frm, b->d_slots};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 2; i++) {
         if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]);
@@ -202,6 +212,10 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_msflag, S * NG);
     ALLOC(b->d_msdec, sizeof(int) * S * NG);
     ALLOC(b->d_thrprev, sizeof(float) * S * 128);
+    ALLOC(b->d_ixq, sizeof(short) * S * NG * 1152);
+    ALLOC(b->d_seg, sizeof(HxSegOut) * S * NG * 2);
+    ALLOC(b->d_frm, sizeof(HxFrameOut) * S * NG);
+    ALLOC(b->d_slots, sizeof(HxSlot) * S * (NG + HX_SLOTS_EXTRA));
     ALLOC(b->d_eng, sizeof(int) * S * 2 * NG * 9);
     ALLOC(b->d_msbase, sizeof(int) * S * NG);
     ALLOC(b->d_flg, S * NG);
@@ -431,8 +445,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
     if (b->debug && b->d_xrdbg) HIPCHK(hipMemcpyAsync(b->d_xrdbg, x_xr, sizeof(float) * (size_t) S * NG * 1152, hipMemcpyDeviceToDevice, q));
     LAUNCH(k_msscan, dim3(S), dim3(64), q, b->d_st, b->d_prm, x_msbase, x_bt, x_msflag, x_msdec, x_thr, x_thrprev, NG, b->lsf);
-    LAUNCH(k_prep, dim3((unsigned) ((long long) S * NG)), dim3(64), q, x_xr, x_x34, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
-           x_etab, x_thr, x_thrprev, NG);
+    LAUNCH(k_prep, dim3((unsigned) (((long long) S * NG + 3) / 4)), dim3(256), q, x_xr, x_x34, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
+           x_etab, x_thr, x_thrprev, NG, (long long) S * NG);
     // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
     LAUNCH(k_carry, dim3(S * 2), dim3(256), q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
     if (pipelined) {
@@ -446,6 +460,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
     a.done_counter = b->d_done;
     a.x34 = x_x34; a.sgn = x_sgn; a.band = x_band; a.msflag = x_msflag; a.msdec = x_msdec; a.thrprev = x_thrprev;
+    a.ixq = b->d_ixq; a.sgn_w = x_sgn; a.seg = b->d_seg; a.frm = b->d_frm; a.slots = b->d_slots;
     b->alloc_launches++;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
@@ -455,6 +470,13 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     else LAUNCH(k_alloc, dim3(S), dim3(128), qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
+    {   // every frame of the call packed at once, then the incomplete frames' images into the stream state
+        const int fps = (b->lsf ? 2 : 1) * nframes;
+        LAUNCH(k_pack, dim3((unsigned) ((long long) S * fps)), dim3(256), qa, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
+               (const short *) b->d_ixq, (const unsigned char *) x_sgn, (const HxSegOut *) b->d_seg, (const HxFrameOut *) b->d_frm, (const HxSlot *) b->d_slots,
+               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf);
+        LAUNCH(k_pack_carry, dim3(S), dim3(64), qa, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes);
+    }
     while (b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events
         const auto old = b->pending.front();
         if (hipEventQuery(old.second) != hipSuccess) break;
@@ -724,6 +746,10 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "x34") { src = b->d_x34; n = sizeof(float) * S * NG * 1152; }
     else if (k == "band") { src = b->d_band; n = sizeof(HxBandPrep) * S * NG; }
     else if (k == "msflag") { src = b->d_msflag; n = S * NG; }
+    else if (k == "ixq") { src = b->d_ixq; n = sizeof(short) * S * NG * 1152; }
+    else if (k == "sgn") { src = b->d_sgn; n = S * NG * 1152; }
+    else if (k == "seg") { src = b->d_seg; n = sizeof(HxSegOut) * S * NG * 2; }
+    else if (k == "frm") { src = b->d_frm; n = sizeof(HxFrameOut) * S * NG; }
     else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }
     else if (k == "thr") { src = b->d_thr; n = sizeof(float) * S * NG * 128; }
     else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }

@@ -638,27 +638,37 @@ __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const 
 // (:878-896, pow34.c:132-186), and the masking thresholds after pre-echo control (spdsmr.c:275-318).  The
 // magnitudes replace the spectrum in place; short-block granules are left as they are (their allocator starts
 // from the raw spectrum).
-__global__ __launch_bounds__(64) void k_prep(float *__restrict__ xr, float *__restrict__ x34o, unsigned char *__restrict__ sgn,
+#define PREP_GPB 4      // granules (wavefronts) per workgroup: they share one copy of the lookup tables
+__global__ __launch_bounds__(64 * PREP_GPB) void k_prep(float *__restrict__ xr, float *__restrict__ x34o, unsigned char *__restrict__ sgn,
                                              HxBandPrep *__restrict__ band, const HxStream *__restrict__ st,
                                              const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
                                              const unsigned char *__restrict__ bt, const unsigned char *__restrict__ msflag,
                                              const float *__restrict__ etab, const float *__restrict__ thr,
-                                             const float *__restrict__ thrprev, int NG)
+                                             const float *__restrict__ thrprev, int NG, long long nunits)
 {
-    __shared__ __attribute__((aligned(16))) float xa[2][576];   // magnitudes
-    __shared__ __attribute__((aligned(16))) float ta[2][576];   // squares of L, R
-    __shared__ __attribute__((aligned(16))) float tb[2][576];   // squares of M, S; then x^(3/4)
-    __shared__ __attribute__((aligned(16))) unsigned char sg[2][576];
-    __shared__ int xmax[2][22];
-    const int lane = threadIdx.x;
-    const long long unit = blockIdx.x;          // (s, g)
+    // Per wave only the squares that the band lanes add up live in LDS (one pair of channels at a time: L / R, then
+    // M / S); magnitudes, x^(3/4) and signs stay in the registers of the lane that owns the lines, from the load
+    // to the store.  The gather tables are staged once per workgroup.
+    __shared__ __attribute__((aligned(16))) float sq[PREP_GPB][2][576];
+    __shared__ int xmax[PREP_GPB][2][22];
+    __shared__ float t_exp[256], t_a[16], t_b[16];
+    __shared__ int t_mblog[256];
+    for (int i = threadIdx.x; i < 256; i += 64 * PREP_GPB) { t_exp[i] = gt->pow34_exp[i]; t_mblog[i] = gt->mblog[i]; }
+    if (threadIdx.x < 16) { t_a[threadIdx.x] = gt->pow34_a[threadIdx.x]; t_b[threadIdx.x] = gt->pow34_b[threadIdx.x]; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 44) xmax[wv][lane / 22][lane % 22] = 0;
+    __syncthreads();
+    const long long unit = (long long) blockIdx.x * PREP_GPB + wv;      // (s, g)
+    if (unit >= nunits) return;
     const int g = (int) (unit % NG), s = (int) (unit / NG);
     const int btype = bt[unit];
     if (btype == 2) return;
+    // (from here on the wave works alone: LDS hand-overs inside a wave need no workgroup barrier)
+#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
     const int ms = msflag[unit];
     const int two = p->nchan == 2;
-    const int nsf0 = p->nsf[0], nsf1 = two ? p->nsf[1] : 0;
+    const int nsf0 = p->nsf[0];
     // lines that get magnitudes / x^(3/4), bands that get energies / maxima (reference: nbmax, nbmax2 / nbmax3 ...)
     const int nl_mag0 = ms ? (p->hf_flag ? p->startBand_l[22] : p->nbmax[0]) : p->nbmax3[0];
     const int nl_mag1 = ms ? nl_mag0 : (two ? p->nbmax3[1] : 0);
@@ -666,8 +676,11 @@ __global__ __launch_bounds__(64) void k_prep(float *__restrict__ xr, float *__re
     const int nb_e0 = ms ? nsf0 : p->nsf3[0], nb_e1 = ms ? nsf0 : (two ? p->nsf3[1] : 0);
     const int nb_z0 = ms ? p->nsf2[0] : p->nsf3[0], nb_z1 = two ? (ms ? p->nsf2[1] : p->nsf3[1]) : 0;
     float *x = xr + unit * 1152;
-    if (lane < 44) xmax[lane / 22][lane % 22] = 0;
-    {   // lines: 16 bytes per lane and load, both channels of a line in the same lane
+    float (*sqw)[576] = sq[wv];
+    // lane l owns lines 4 (l + 64 k) .. + 3 of both channels, k = 0..2 (144 groups of four per channel)
+    float a0[3][4], a1[3][4];           // magnitudes in the coded representation
+    unsigned s0[3], s1[3];              // sign bytes
+    {
         float4 lv[3], rv[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -678,86 +691,80 @@ __global__ __launch_bounds__(64) void k_prep(float *__restrict__ xr, float *__re
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int e = lane + 64 * k;
-            if (e >= 144) continue;
             const float l4[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w}, r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-            float a0[4], a1[4], t0[4], t1[4], u0[4], u1[4];
-            unsigned s0 = 0, s1 = 0;
+            float t0[4], t1[4];
+            s0[k] = s1[k] = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int j = 4 * e + c;
                 const float l = l4[c], r = r4[c];
-                a0[c] = l; a1[c] = r; t0[c] = t1[c] = u0[c] = u1[c] = 0.0f;
+                a0[k][c] = l; a1[k][c] = r; t0[c] = t1[c] = 0.0f;
                 if (ms) {
                     if (j < nl_mag0) {
                         t0[c] = l * l;
                         t1[c] = r * r;
                         float m = (l + r), d = (l - r);
-                        if (m < 0.0f) { s0 |= 1u << (8 * c); m = -m; }
-                        if (d < 0.0f) { s1 |= 1u << (8 * c); d = -d; }
-                        a0[c] = m; a1[c] = d;
-                        u0[c] = m * m;
-                        u1[c] = d * d;
+                        if (m < 0.0f) { s0[k] |= 1u << (8 * c); m = -m; }
+                        if (d < 0.0f) { s1[k] |= 1u << (8 * c); d = -d; }
+                        a0[k][c] = m; a1[k][c] = d;
                     }
                 } else {
-                    if (j < nl_mag0) { float v = l; if (!(v >= 0.0f)) { s0 |= 1u << (8 * c); v = -v; } a0[c] = v; t0[c] = v * v; }
-                    if (j < nl_mag1) { float v = r; if (!(v >= 0.0f)) { s1 |= 1u << (8 * c); v = -v; } a1[c] = v; t1[c] = v * v; }
+                    if (j < nl_mag0) { float v = l; if (!(v >= 0.0f)) { s0[k] |= 1u << (8 * c); v = -v; } a0[k][c] = v; t0[c] = v * v; }
+                    if (j < nl_mag1) { float v = r; if (!(v >= 0.0f)) { s1[k] |= 1u << (8 * c); v = -v; } a1[k][c] = v; t1[c] = v * v; }
                 }
             }
-            reinterpret_cast<float4 *>(xa[0])[e] = make_float4(a0[0], a0[1], a0[2], a0[3]);
-            reinterpret_cast<float4 *>(xa[1])[e] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-            reinterpret_cast<float4 *>(ta[0])[e] = make_float4(t0[0], t0[1], t0[2], t0[3]);
-            reinterpret_cast<float4 *>(ta[1])[e] = make_float4(t1[0], t1[1], t1[2], t1[3]);
-            reinterpret_cast<float4 *>(tb[0])[e] = make_float4(u0[0], u0[1], u0[2], u0[3]);
-            reinterpret_cast<float4 *>(tb[1])[e] = make_float4(u1[0], u1[1], u1[2], u1[3]);
-            reinterpret_cast<unsigned *>(sg[0])[e] = s0;
-            reinterpret_cast<unsigned *>(sg[1])[e] = s1;
+            if (e < 144) {
+                reinterpret_cast<float4 *>(sqw[0])[e] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+                reinterpret_cast<float4 *>(sqw[1])[e] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+            }
         }
     }
-    __syncthreads();
-    // band energies: lane (ch, sfb) adds its band's squares in line order
+    WAVE_SYNC();
+    // band energies: lane (ch, sfb) adds its band's squares in line order - L / R first, then (joint stereo) M / S
     const int ch = lane >> 5, i = lane & 31;
     const int cbw = (i < 22) ? p->look_log_cbwmb[i] : 0;
+    const bool eband = i < (ch ? nb_e1 : nb_e0);
+    const int b0 = eband ? p->startBand_l[i] : 0, bn = eband ? p->nBand_l[i] : 0;
     float e_lr = 0.0f;
     int n0 = 0, n0ms = 0;
-    if (i < (ch ? nb_e1 : nb_e0)) {
-        const int b0 = p->startBand_l[i], n = p->nBand_l[i];
-        if (ms) {
-            float e_ms;
-            band_sum2(&ta[ch][b0], &tb[ch][b0], n, &e_lr, &e_ms);
-            n0ms = hx_mblog(gt->mblog, e_ms) - cbw;
-        } else e_lr = band_sum(&ta[ch][b0], n, 0.0f);
-        n0 = hx_mblog(gt->mblog, e_lr) - cbw;
+    if (eband) {
+        e_lr = band_sum(&sqw[ch][b0], bn, 0.0f);
+        n0 = hx_mblog(t_mblog, e_lr) - cbw;
     }
-    __syncthreads();        // tb is reused for x^(3/4)
-    {   // x^(3/4) of the coded magnitudes and the band maxima (bit patterns of non-negative floats order like integers)
+    if (ms) {
+        WAVE_SYNC();
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int e = lane + 64 * k;
-            if (e >= 144) continue;
-#pragma unroll
-            for (int c2 = 0; c2 < 2; c2++) {
-                const float4 v = reinterpret_cast<const float4 *>(xa[c2])[e];
-                const float m4[4] = {v.x, v.y, v.z, v.w};
-                float q[4];
-                const int nl = c2 ? nl_p1 : nl_p0;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int j = 4 * e + c;
-                    q[c] = 0.0f;
-                    if (j < nl) {
-                        q[c] = hx_pow34(gt->pow34_a, gt->pow34_b, gt->pow34_exp, m4[c]);
-                        atomicMax(&xmax[c2][p->band_of_line[j]], __float_as_int(q[c]));
-                    }
-                }
-                reinterpret_cast<float4 *>(tb[c2])[e] = make_float4(q[0], q[1], q[2], q[3]);
+            if (e < 144) {
+                // (lines past nl_mag0 were left raw above; their squares are never summed)
+                reinterpret_cast<float4 *>(sqw[0])[e] = make_float4(a0[k][0] * a0[k][0], a0[k][1] * a0[k][1], a0[k][2] * a0[k][2], a0[k][3] * a0[k][3]);
+                reinterpret_cast<float4 *>(sqw[1])[e] = make_float4(a1[k][0] * a1[k][0], a1[k][1] * a1[k][1], a1[k][2] * a1[k][2], a1[k][3] * a1[k][3]);
             }
         }
+        WAVE_SYNC();
+        if (eband) n0ms = hx_mblog(t_mblog, band_sum(&sqw[ch][b0], bn, 0.0f)) - cbw;
     }
-    __syncthreads();
+    // x^(3/4) of the coded magnitudes and the band maxima (bit patterns of non-negative floats order like integers)
+    float q0[3][4], q1[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int e = lane + 64 * k;
+        unsigned bl = 0;
+        if (e < 144) bl = reinterpret_cast<const unsigned *>(p->band_of_line)[e];       // the four lines' bands
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = 4 * e + c, bnd = (bl >> (8 * c)) & 255;
+            q0[k][c] = q1[k][c] = 0.0f;
+            if (e < 144 && j < nl_p0) { q0[k][c] = hx_pow34(t_a, t_b, t_exp, a0[k][c]); atomicMax(&xmax[wv][0][bnd], __float_as_int(q0[k][c])); }
+            if (e < 144 && j < nl_p1) { q1[k][c] = hx_pow34(t_a, t_b, t_exp, a1[k][c]); atomicMax(&xmax[wv][1][bnd], __float_as_int(q1[k][c])); }
+        }
+    }
+    WAVE_SYNC();
     int gz = 0;
     float xm = 0.0f;
-    if (i < 22) xm = __int_as_float(xmax[ch][i]);
-    if (i < (ch ? nb_z1 : nb_z0)) gz = max(0, hx_round((0.017716950f * hx_mblog(gt->mblog, xm) + (104.585000f - 100.0f + 8.0f))));
+    if (i < 22) xm = __int_as_float(xmax[wv][ch][i]);
+    if (i < (ch ? nb_z1 : nb_z0)) gz = max(0, hx_round((0.017716950f * hx_mblog(t_mblog, xm) + (104.585000f - 100.0f + 8.0f))));
     // masking threshold of the band: the two partitions' thresholds, each clamped against twice the previous
     // granule's unless this is a stop block, weighted by the partitions' energies
     int mmb = 0;
@@ -765,34 +772,38 @@ __global__ __launch_bounds__(64) void k_prep(float *__restrict__ xr, float *__re
         const float2 th = reinterpret_cast<const float2 *>(thr + unit * 128 + ch * 64)[i];
         const float2 en = reinterpret_cast<const float2 *>(etab + unit * 128 + ch * 64)[i];
         const float2 pv = reinterpret_cast<const float2 *>((g == 0 ? thrprev + (long long) s * 128 : thr + (unit - 1) * 128) + ch * 64)[i];
-        float s1 = th.x, s2 = th.y;
+        float s1v = th.x, s2v = th.y;
         const float t1 = (g == 0) ? pv.x : 2.0f * pv.x, t2 = (g == 0) ? pv.y : 2.0f * pv.y;
         if (btype != 3) {
-            if (s1 > t1) { const float f = 0.1f * s1; s1 = t1; if (s1 < f) s1 = f; }
-            if (s2 > t2) { const float f = 0.1f * s2; s2 = t2; if (s2 < f) s2 = f; }
+            if (s1v > t1) { const float f = 0.1f * s1v; s1v = t1; if (s1v < f) s1v = f; }
+            if (s2v > t2) { const float f = 0.1f * s2v; s2v = t2; if (s2v < f) s2v = f; }
         }
         float emax = en.x;
         if (emax < en.y) emax = en.y;
-        mmb = hx_mblog(gt->mblog, (en.x * s1 + en.y * s2) / emax);
+        mmb = hx_mblog(t_mblog, (en.x * s1v + en.y * s2v) / emax);
     }
     HxBandPrep *bp = band + unit;
     if (i < 22) {
         bp->xsxx[ch][i] = e_lr; bp->x34max[ch][i] = xm; bp->n0[ch][i] = n0; bp->n0ms[ch][i] = n0ms;
         bp->gzero[ch][i] = gz; bp->maskmb[ch][i] = mmb;
     }
-    {   // magnitudes over the spectrum, x^(3/4) and signs to their buffers: 16 bytes per lane and store
+    {   // magnitudes over the spectrum, x^(3/4) and signs to their buffers, straight from the owning lanes
         float4 *dx = reinterpret_cast<float4 *>(x), *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);
-        const float4 *sx = reinterpret_cast<const float4 *>(&xa[0][0]), *sq = reinterpret_cast<const float4 *>(&tb[0][0]);
+        unsigned *ds = reinterpret_cast<unsigned *>(sgn + unit * 1152);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 3; k++) {
             const int e = lane + 64 * k;
-            if (e < 288) { dx[e] = sx[e]; dq[e] = sq[e]; }
+            if (e < 144) {
+                dx[e] = make_float4(a0[k][0], a0[k][1], a0[k][2], a0[k][3]);
+                dx[144 + e] = make_float4(a1[k][0], a1[k][1], a1[k][2], a1[k][3]);
+                dq[e] = make_float4(q0[k][0], q0[k][1], q0[k][2], q0[k][3]);
+                dq[144 + e] = make_float4(q1[k][0], q1[k][1], q1[k][2], q1[k][3]);
+                ds[e] = s0[k];
+                ds[144 + e] = s1[k];
+            }
         }
-        uint4 *ds = reinterpret_cast<uint4 *>(sgn + unit * 1152);
-        const uint4 *ss4 = reinterpret_cast<const uint4 *>(&sg[0][0]);
-        ds[lane] = ss4[lane];
-        if (lane < 8) ds[64 + lane] = ss4[64 + lane];
     }
+#undef WAVE_SYNC
 }
 
 // After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the

@@ -1,0 +1,208 @@
+// hx_pack.hip - K7: bitstream packing of the batched MP3 encoder for MI355X (gfx950), one workgroup per frame.
+//
+// The allocator kernel (hx_alloc*.hip) walks a stream's frames in order because its state is carried from frame
+// to frame; writing the bits is not part of that chain.  It leaves, per (granule, channel), the quantised
+// lines, the scalefactor fields and the Huffman regions, with the bit position where the segment starts in its
+// frame's main data (known from the bit counts), and per frame where the main data goes in the output.  Here
+// every frame of the batch is packed at the same time: wave w of a frame's workgroup writes segment w
+// (granule w / 2, channel w % 2) into an LDS bit buffer - code words built five pairs per lane, placed with a
+// wave prefix sum of their lengths, OR-ed in with LDS atomics - and the workgroup then moves the bytes to their
+// place in the pending frames' slots (reference l3pack.c:157-558 scalefactors, :946-1119 Huffman codes,
+// mp3enc.cpp:2258-2325 frame assembly).
+#include "hx_dev.h"
+
+struct alignas(16) PackLds {
+    unsigned bitw[640];                 // the frame's main data, MSB-first 32-bit words
+    unsigned short ix[4][576];          // per segment: quantised magnitudes ...
+    unsigned char sg[4][576];           // ... and signs
+    unsigned short huff_code[1408];
+    unsigned char huff_len[1408];
+    int tabpk[32];                      // per Huffman table: code offset | row stride << 12 | linbits << 20
+    unsigned char quada_code[16], quada_len[16];
+};
+
+// OR an n-bit field (n <= 32) at absolute bit position pos
+__device__ __forceinline__ void put_bits(PackLds &L, int pos, unsigned val, int n)
+{
+    if (n <= 0) return;
+    const int w = pos >> 5, o = pos & 31;
+    const unsigned long long v = ((unsigned long long) val) << (64 - n - o);    // field left-aligned in 64 bits at offset o
+    const unsigned hi = (unsigned) (v >> 32), lo = (unsigned) v;
+    if (hi) atomicOr(&L.bitw[w], hi);
+    if (lo) atomicOr(&L.bitw[w + 1], lo);
+}
+__device__ __forceinline__ void put_bits64(PackLds &L, int pos, unsigned long long val, int n)
+{
+    if (n > 32) { put_bits(L, pos, (unsigned) (val >> 32), n - 32); put_bits(L, pos + n - 32, (unsigned) val, 32); }
+    else put_bits(L, pos, (unsigned) val, n);
+}
+
+// Huffman-code one segment; returns the new bit position.  Phase A builds the code word of every pair (five per
+// lane, table parameters of the three regions read once and picked with selects: independent chains, no
+// branches); phase B places them with a wave prefix sum of the lengths per 64 pairs.  Then the count1 quads.
+__device__ __forceinline__ int pack_huff(PackLds &L, int pos, const HxSegOut *sg, const unsigned short *ix, const unsigned char *sgn, int lane)
+{
+    const int n0 = sg->nreg[0], n1 = sg->nreg[1], n2 = sg->nreg[2];
+    const int npairs = n0 + n1 + n2;
+    const int pk0 = L.tabpk[sg->tab[0]], pk1 = L.tabpk[sg->tab[1]], pk2 = L.tabpk[sg->tab[2]];
+    unsigned long long val[5];
+    int len[5];
+    {
+        unsigned xy[5], sn[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int pc = min(lane + 64 * k, 287);
+            xy[k] = reinterpret_cast<const unsigned *>(ix)[pc];
+            sn[k] = reinterpret_cast<const unsigned short *>(sgn)[pc];
+        }
+        int o[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int pi = lane + 64 * k;
+            const int pk = (pi < n0) ? pk0 : (pi < n0 + n1 ? pk1 : pk2);
+            o[k] = (pk & 0xFFF) + min((int) (xy[k] & 0xFFFF), 15) * ((pk >> 12) & 0xFF) + min((int) (xy[k] >> 16), 15);
+        }
+        unsigned code[5], hl[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { code[k] = L.huff_code[o[k]]; hl[k] = L.huff_len[o[k]]; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int pi = lane + 64 * k;
+            const int pk = (pi < n0) ? pk0 : (pi < n0 + n1 ? pk1 : pk2);
+            const int dim = (pk >> 12) & 0xFF, lin = pk >> 20, x = (int) (xy[k] & 0xFFFF), y = (int) (xy[k] >> 16);
+            unsigned long long v = code[k];
+            int l = (int) hl[k];
+            const int lx = (x >= 15) ? lin : 0, ly = (y >= 15) ? lin : 0;       // escapes (lin = 0 below table 16)
+            v = (v << lx) | (unsigned) ((x >= 15) ? x - 15 : 0);
+            l += lx;
+            if (x) { v = (v << 1) | (sn[k] & 1u); l++; }
+            v = (v << ly) | (unsigned) ((y >= 15) ? y - 15 : 0);
+            l += ly;
+            if (y) { v = (v << 1) | ((sn[k] >> 8) & 1u); l++; }
+            val[k] = v;
+            len[k] = (pi < npairs && dim != 0) ? l : 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (64 * k < npairs) {
+            const int incl = hx_wave_scan(len[k]);
+            if (len[k]) put_bits64(L, pos + incl - len[k], val[k], len[k]);
+            pos += __builtin_amdgcn_readlane(incl, 63);
+        }
+    }
+    const int nq = sg->nquads, qb = 2 * npairs;
+    const int c1sel = sg->c1sel;
+    unsigned qval[3];
+    int qlen[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int q = lane + 64 * k, qc = min(q, max(nq - 1, 0));
+        const unsigned *v2 = reinterpret_cast<const unsigned *>(ix + qb + 4 * qc);
+        const unsigned a = v2[0], b = v2[1];
+        const unsigned short *s2 = reinterpret_cast<const unsigned short *>(sgn + qb + 4 * qc);
+        const unsigned s4 = (unsigned) s2[0] | ((unsigned) s2[1] << 16);
+        const int code = (int) (((a & 0xFFFF) << 3) + ((a >> 16) << 2) + ((b & 0xFFFF) << 1) + (b >> 16));
+        unsigned v;
+        int l;
+        if (c1sel == 1) { v = code ^ 15; l = 4; }
+        else { v = L.quada_code[code & 15]; l = L.quada_len[code & 15]; }
+        if (code & 8) { v = (v << 1) | (s4 & 1u); l++; }
+        if (code & 4) { v = (v << 1) | ((s4 >> 8) & 1u); l++; }
+        if (code & 2) { v = (v << 1) | ((s4 >> 16) & 1u); l++; }
+        if (code & 1) { v = (v << 1) | ((s4 >> 24) & 1u); l++; }
+        qval[k] = v;
+        qlen[k] = (q < nq) ? l : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (64 * k < nq) {
+            const int incl = hx_wave_scan(qlen[k]);
+            if (qlen[k]) put_bits(L, pos + incl - qlen[k], qval[k], qlen[k]);
+            pos += __builtin_amdgcn_readlane(incl, 63);
+        }
+    }
+    return pos;
+}
+
+// frames_per_stream = frames a stream produces per call (nframes, or 2 nframes at the MPEG-2 rates where every
+// granule is a frame); lsf selects that layout.
+__global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, const HxParams *__restrict__ prm,
+                                              const HxGlobalTabs *__restrict__ gt, const short *__restrict__ ixq,
+                                              const unsigned char *__restrict__ sgn, const HxSegOut *__restrict__ seg,
+                                              const HxFrameOut *__restrict__ frm, const HxSlot *__restrict__ slots,
+                                              unsigned char *__restrict__ out, long long out_stride, unsigned char *__restrict__ packet,
+                                              int *__restrict__ status, int frames_per_stream, int NG, int lsf)
+{
+    __shared__ PackLds L;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long fr = blockIdx.x;
+    const int s = (int) (fr / frames_per_stream), f = (int) (fr % frames_per_stream);
+    for (int i = tid; i < 1408; i += 256) { L.huff_code[i] = gt->huff_code[i]; L.huff_len[i] = gt->huff_len[i]; }
+    for (int i = tid; i < 640; i += 256) L.bitw[i] = 0;
+    if (tid < 32) {
+        const int dim = (tid >= 16) ? 16 : gt->huff_dim[tid], lin = (tid >= 16) ? gt->huff_lin[tid] : 0;
+        L.tabpk[tid] = gt->huff_off[tid] | (dim << 12) | (lin << 20);
+    }
+    if (tid < 16) { L.quada_code[tid] = gt->quada_code[tid]; L.quada_len[tid] = gt->quada_len[tid]; }
+    const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
+    const int nchan = p->nchan, hdr = 4 + p->side_bytes;
+    // wave w <-> segment (granule, channel)
+    const int g = lsf ? f : 2 * f + (w >> 1), ch = w & 1;
+    const bool mine = (lsf ? w < 2 : true) && ch < nchan;
+    const long long unit = ((long long) s * NG + g) * 2 + ch;
+    const HxSegOut *so = seg + unit;
+    int not_null = 0;
+    if (mine) {
+        not_null = so->not_null;
+        if (not_null) {      // lines and signs into this wave's LDS copy, 16 bytes per lane and load
+            const uint4 *sx = reinterpret_cast<const uint4 *>(ixq + unit * 576);
+            const uint4 *ss = reinterpret_cast<const uint4 *>(sgn + unit * 576);
+            uint4 *dx = reinterpret_cast<uint4 *>(&L.ix[w][0]), *ds = reinterpret_cast<uint4 *>(&L.sg[w][0]);
+            dx[lane] = sx[lane];
+            if (lane < 8) dx[64 + lane] = sx[64 + lane];
+            if (lane < 36) ds[lane] = ss[lane];
+        }
+    }
+    __syncthreads();
+    if (mine) {
+        int pos = so->start_bit;
+        {   // scalefactor fields in transmission order
+            const int fld = (lane < 40) ? so->sf[lane] : 0, len = fld >> 8;
+            const int incl = hx_wave_scan(len);
+            if (len) put_bits(L, pos + incl - len, (unsigned) (fld & 255), len);
+            pos += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (not_null) {
+            const int h0 = pos;
+            pos = pack_huff(L, pos, so, L.ix[w], L.sg[w], lane);
+            if (pos - h0 != so->huff_bits && lane == 0) atomicOr(status, 4);     // counted and packed Huffman bits must agree
+        }
+    }
+    __syncthreads();
+    // the frame's main data (zero stuffing up to byte_min included) into the pending slots, oldest first
+    const HxFrameOut fo = frm[fr];
+    const HxSlot *sl = slots + (long long) s * (frames_per_stream + HX_SLOTS_EXTRA);
+    unsigned char *o = out + (long long) s * out_stride;
+    for (int i = tid; i < fo.bytes; i += 256) {
+        const unsigned char v = (i < fo.raw_bytes) ? (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3))) : 0;
+        int q = fo.main_bytes + i, k = fo.first_slot;
+        int cap = sl[k].mf;
+        while (q >= cap) { q -= cap; k++; cap = sl[k].mf; }
+        o[sl[k].off + hdr + q] = v;
+    }
+    if (fo.packet_off >= 0)     // *_Packet outputs: the unpadded main data behind the packet's own header and side info
+        for (int i = tid; i < fo.raw_bytes; i += 256) packet[fo.packet_off + i] = (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3)));
+}
+
+// Frames whose slot is not full yet travel to the next call in the stream state: their images (headers, side
+// information, the main data written so far) follow the complete frames in `out`.
+__global__ __launch_bounds__(64) void k_pack_carry(HxStream *__restrict__ st, const unsigned char *__restrict__ out, long long out_stride,
+                                                   const int *__restrict__ out_bytes)
+{
+    const int s = blockIdx.x;
+    HxStream *ss = st + s;
+    const unsigned char *src = out + (long long) s * out_stride + out_bytes[s];
+    const int n = ss->main_p1;
+    for (int i = threadIdx.x; i < n; i += 64) ss->main_buf[i] = src[i];
+}

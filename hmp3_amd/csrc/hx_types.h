@@ -142,6 +142,26 @@ struct HxFrameDebug {
     int main_bytes;             // bytes of main data produced by this frame (before padding)
 };
 
+// ---- k_alloc -> k_pack hand-over: what the packer needs of a coded frame ----
+// One (granule, channel): where its bits start in the frame's main data, the scalefactor fields in transmission
+// order, the Huffman regions.  The quantised lines travel as int16 beside it.
+struct alignas(8) HxSegOut {
+    int start_bit;              // first bit of the segment within the frame's main data
+    int huff_bits;              // Huffman bits counted by the allocator (the packer checks them)
+    unsigned short nreg[3];     // pairs per region
+    unsigned short nquads;
+    unsigned char tab[3], c1sel, not_null, pad[3];
+    unsigned short sf[40];      // (length << 8) | value of each transmitted scalefactor field
+};
+// One frame: its main data spans the pending slots from first_slot on (the first one has main_bytes bytes in use)
+struct HxFrameOut {
+    int bytes, raw_bytes;       // main data bytes with / without the zero stuffing up to byte_min
+    int first_slot, main_bytes;
+    long long packet_off;       // offset of the frame's main data in the packet buffer, -1 = no packet
+};
+struct HxSlot { int off, mf; };     // a frame's slot in a stream's output: offset of its header, main-data bytes it holds
+#define HX_SLOTS_EXTRA 40           // slots pending from earlier calls (the ring holds 32)
+
 // Arguments of the allocator kernels (k_alloc / k_alloc_lsf), filled by the host runtime.
 struct AllocArgs {
     HxStream *st;
@@ -171,5 +191,11 @@ struct AllocArgs {
     const unsigned char *msflag;    // [S][NG] 1 = the granule's frame is coded M/S
     const int *msdec;           // [S][NG] the stereo metric after hysteresis (debug taps)
     const float *thrprev;       // [S][2][64] pre-echo memory the call started with
+    // to k_pack (hx_pack.hip)
+    short *ixq;                 // [S][NG][2][576] quantised magnitudes
+    unsigned char *sgn_w;       // the sign buffer again, writable: short-block granules store their reordered signs
+    HxSegOut *seg;              // [S][NG][2]
+    HxFrameOut *frm;            // [S][frames per call]
+    HxSlot *slots;              // [S][frames per call + HX_SLOTS_EXTRA]
 };
 
