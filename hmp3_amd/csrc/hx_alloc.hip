@@ -46,6 +46,8 @@ struct alignas(16) AllocLds {
     float term[2][576];
     int ix[2][576];
     unsigned char signx[2][576];
+    alignas(16) unsigned char sgn_next[2][576];     // the next granule's signs and band start values, landed by LDS-DMA while
+    HxBandPrep band_next;                           // this granule's copies are still in use
     unsigned char band_of_line[576];
     // tables staged from global memory
     float look_ix43[256], look_gain[128], look_34igain[128];
@@ -137,7 +139,7 @@ struct alignas(16) AllocLds {
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_PACK, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_FETCH };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \

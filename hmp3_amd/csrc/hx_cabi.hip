@@ -30,7 +30,7 @@ __global__ void k_prep(float *xr, float *x34o, unsigned char *sgn, HxBandPrep *b
                        const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG, long long nunits);
 __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned char *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
-                       int frames_per_stream, int NG, int lsf);
+                       int frames_per_stream, int NG, int lsf, long long nframes_total);
 __global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
@@ -472,9 +472,10 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     b->pending.push_back({e0, e1});
     {   // every frame of the call packed at once, then the incomplete frames' images into the stream state
         const int fps = (b->lsf ? 2 : 1) * nframes;
-        LAUNCH(k_pack, dim3((unsigned) ((long long) S * fps)), dim3(256), qa, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
+        const long long total = (long long) S * fps;
+        LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qa, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
                (const short *) b->d_ixq, (const unsigned char *) x_sgn, (const HxSegOut *) b->d_seg, (const HxFrameOut *) b->d_frm, (const HxSlot *) b->d_slots,
-               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf);
+               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total);
         LAUNCH(k_pack_carry, dim3(S), dim3(64), qa, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes);
     }
     while (b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events

@@ -40,11 +40,11 @@ __device__ __forceinline__ void put_bits64(PackLds &L, int pos, unsigned long lo
 // Huffman-code one segment; returns the new bit position.  Phase A builds the code word of every pair (five per
 // lane, table parameters of the three regions read once and picked with selects: independent chains, no
 // branches); phase B places them with a wave prefix sum of the lengths per 64 pairs.  Then the count1 quads.
-__device__ __forceinline__ int pack_huff(PackLds &L, int pos, const HxSegOut *sg, const unsigned short *ix, const unsigned char *sgn, int lane)
+__device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsigned r2q, unsigned tabs, const unsigned short *ix, const unsigned char *sgn, int lane)
 {
-    const int n0 = sg->nreg[0], n1 = sg->nreg[1], n2 = sg->nreg[2];
+    const int n0 = r01 & 0xFFFF, n1 = r01 >> 16, n2 = r2q & 0xFFFF;
     const int npairs = n0 + n1 + n2;
-    const int pk0 = L.tabpk[sg->tab[0]], pk1 = L.tabpk[sg->tab[1]], pk2 = L.tabpk[sg->tab[2]];
+    const int pk0 = L.tabpk[tabs & 31], pk1 = L.tabpk[(tabs >> 8) & 31], pk2 = L.tabpk[(tabs >> 16) & 31];
     unsigned long long val[5];
     int len[5];
     {
@@ -91,8 +91,8 @@ __device__ __forceinline__ int pack_huff(PackLds &L, int pos, const HxSegOut *sg
             pos += __builtin_amdgcn_readlane(incl, 63);
         }
     }
-    const int nq = sg->nquads, qb = 2 * npairs;
-    const int c1sel = sg->c1sel;
+    const int nq = (int) (r2q >> 16), qb = 2 * npairs;
+    const int c1sel = (int) (tabs >> 24);
     unsigned qval[3];
     int qlen[3];
 #pragma unroll
@@ -126,73 +126,82 @@ __device__ __forceinline__ int pack_huff(PackLds &L, int pos, const HxSegOut *sg
 }
 
 // frames_per_stream = frames a stream produces per call (nframes, or 2 nframes at the MPEG-2 rates where every
-// granule is a frame); lsf selects that layout.
+// granule is a frame); lsf selects that layout.  The grid is sized to fill the chip once; a workgroup stages the
+// code tables once and then takes every gridDim.x-th frame.
 __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, const HxParams *__restrict__ prm,
                                               const HxGlobalTabs *__restrict__ gt, const short *__restrict__ ixq,
                                               const unsigned char *__restrict__ sgn, const HxSegOut *__restrict__ seg,
                                               const HxFrameOut *__restrict__ frm, const HxSlot *__restrict__ slots,
                                               unsigned char *__restrict__ out, long long out_stride, unsigned char *__restrict__ packet,
-                                              int *__restrict__ status, int frames_per_stream, int NG, int lsf)
+                                              int *__restrict__ status, int frames_per_stream, int NG, int lsf, long long nframes_total)
 {
     __shared__ PackLds L;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long long fr = blockIdx.x;
-    const int s = (int) (fr / frames_per_stream), f = (int) (fr % frames_per_stream);
     for (int i = tid; i < 1408; i += 256) { L.huff_code[i] = gt->huff_code[i]; L.huff_len[i] = gt->huff_len[i]; }
-    for (int i = tid; i < 640; i += 256) L.bitw[i] = 0;
     if (tid < 32) {
         const int dim = (tid >= 16) ? 16 : gt->huff_dim[tid], lin = (tid >= 16) ? gt->huff_lin[tid] : 0;
         L.tabpk[tid] = gt->huff_off[tid] | (dim << 12) | (lin << 20);
     }
     if (tid < 16) { L.quada_code[tid] = gt->quada_code[tid]; L.quada_len[tid] = gt->quada_len[tid]; }
-    const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
-    const int nchan = p->nchan, hdr = 4 + p->side_bytes;
-    // wave w <-> segment (granule, channel)
-    const int g = lsf ? f : 2 * f + (w >> 1), ch = w & 1;
-    const bool mine = (lsf ? w < 2 : true) && ch < nchan;
-    const long long unit = ((long long) s * NG + g) * 2 + ch;
-    const HxSegOut *so = seg + unit;
-    int not_null = 0;
-    if (mine) {
-        not_null = so->not_null;
-        if (not_null) {      // lines and signs into this wave's LDS copy, 16 bytes per lane and load
+    for (long long fr = blockIdx.x; fr < nframes_total; fr += gridDim.x) {
+        const int s = (int) (fr / frames_per_stream), f = (int) (fr % frames_per_stream);
+        for (int i = tid; i < 640; i += 256) L.bitw[i] = 0;
+        const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
+        const int nchan = p->nchan, hdr = 4 + p->side_bytes;
+        // wave w <-> segment (granule, channel)
+        const int g = lsf ? f : 2 * f + (w >> 1), ch = w & 1;
+        const bool mine = (lsf ? w < 2 : true) && ch < nchan;
+        const long long unit = ((long long) s * NG + g) * 2 + ch;
+        const HxSegOut *so = seg + unit;
+        // everything the wave needs of its segment in one round trip: the record's six words, its scalefactor
+        // field, the lines and the signs (requested whether or not the segment turns out to be empty)
+        int4 h0 = make_int4(0, 0, 0, 0);
+        int2 h1 = make_int2(0, 0);
+        int fld = 0;
+        const HxFrameOut fo = frm[fr];
+        if (mine) {
+            h0 = *reinterpret_cast<const int4 *>(so);
+            h1 = reinterpret_cast<const int2 *>(so)[2];
+            if (lane < 40) fld = so->sf[lane];
             const uint4 *sx = reinterpret_cast<const uint4 *>(ixq + unit * 576);
             const uint4 *ss = reinterpret_cast<const uint4 *>(sgn + unit * 576);
             uint4 *dx = reinterpret_cast<uint4 *>(&L.ix[w][0]), *ds = reinterpret_cast<uint4 *>(&L.sg[w][0]);
-            dx[lane] = sx[lane];
-            if (lane < 8) dx[64 + lane] = sx[64 + lane];
-            if (lane < 36) ds[lane] = ss[lane];
+            const uint4 a0 = sx[lane], a1 = sx[64 + (lane & 7)], a2 = ss[min(lane, 35)];
+            dx[lane] = a0;
+            if (lane < 8) dx[64 + lane] = a1;
+            if (lane < 36) ds[lane] = a2;
         }
-    }
-    __syncthreads();
-    if (mine) {
-        int pos = so->start_bit;
-        {   // scalefactor fields in transmission order
-            const int fld = (lane < 40) ? so->sf[lane] : 0, len = fld >> 8;
-            const int incl = hx_wave_scan(len);
-            if (len) put_bits(L, pos + incl - len, (unsigned) (fld & 255), len);
-            pos += __builtin_amdgcn_readlane(incl, 63);
+        const int not_null = h1.y;
+        __syncthreads();
+        if (mine) {
+            int pos = h0.x;                                 // start_bit
+            {   // scalefactor fields in transmission order
+                const int len = fld >> 8;
+                const int incl = hx_wave_scan(len);
+                if (len) put_bits(L, pos + incl - len, (unsigned) (fld & 255), len);
+                pos += __builtin_amdgcn_readlane(incl, 63);
+            }
+            if (not_null) {
+                const int hb = pos;
+                pos = pack_huff(L, pos, (unsigned) h0.z, (unsigned) h0.w, (unsigned) h1.x, L.ix[w], L.sg[w], lane);
+                if (pos - hb != h0.y && lane == 0) atomicOr(status, 4);     // counted and packed Huffman bits must agree
+            }
         }
-        if (not_null) {
-            const int h0 = pos;
-            pos = pack_huff(L, pos, so, L.ix[w], L.sg[w], lane);
-            if (pos - h0 != so->huff_bits && lane == 0) atomicOr(status, 4);     // counted and packed Huffman bits must agree
+        __syncthreads();
+        // the frame's main data (zero stuffing up to byte_min included) into the pending slots, oldest first
+        const HxSlot *sl = slots + (long long) s * (frames_per_stream + HX_SLOTS_EXTRA);
+        unsigned char *o = out + (long long) s * out_stride;
+        for (int i = tid; i < fo.bytes; i += 256) {
+            const unsigned char v = (i < fo.raw_bytes) ? (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3))) : 0;
+            int q = fo.main_bytes + i, k = fo.first_slot;
+            int cap = sl[k].mf;
+            while (q >= cap) { q -= cap; k++; cap = sl[k].mf; }
+            o[sl[k].off + hdr + q] = v;
         }
+        if (fo.packet_off >= 0)     // *_Packet outputs: the unpadded main data behind the packet's own header and side info
+            for (int i = tid; i < fo.raw_bytes; i += 256) packet[fo.packet_off + i] = (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3)));
+        __syncthreads();            // the bit buffer is cleared for the next frame
     }
-    __syncthreads();
-    // the frame's main data (zero stuffing up to byte_min included) into the pending slots, oldest first
-    const HxFrameOut fo = frm[fr];
-    const HxSlot *sl = slots + (long long) s * (frames_per_stream + HX_SLOTS_EXTRA);
-    unsigned char *o = out + (long long) s * out_stride;
-    for (int i = tid; i < fo.bytes; i += 256) {
-        const unsigned char v = (i < fo.raw_bytes) ? (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3))) : 0;
-        int q = fo.main_bytes + i, k = fo.first_slot;
-        int cap = sl[k].mf;
-        while (q >= cap) { q -= cap; k++; cap = sl[k].mf; }
-        o[sl[k].off + hdr + q] = v;
-    }
-    if (fo.packet_off >= 0)     // *_Packet outputs: the unpadded main data behind the packet's own header and side info
-        for (int i = tid; i < fo.raw_bytes; i += 256) packet[fo.packet_off + i] = (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3)));
 }
 
 // Frames whose slot is not full yet travel to the next call in the stream state: their images (headers, side

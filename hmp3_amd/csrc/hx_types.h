@@ -145,12 +145,13 @@ struct HxFrameDebug {
 // ---- k_alloc -> k_pack hand-over: what the packer needs of a coded frame ----
 // One (granule, channel): where its bits start in the frame's main data, the scalefactor fields in transmission
 // order, the Huffman regions.  The quantised lines travel as int16 beside it.
-struct alignas(8) HxSegOut {
+struct alignas(16) HxSegOut {
     int start_bit;              // first bit of the segment within the frame's main data
     int huff_bits;              // Huffman bits counted by the allocator (the packer checks them)
-    unsigned short nreg[3];     // pairs per region
-    unsigned short nquads;
-    unsigned char tab[3], c1sel, not_null, pad[3];
+    unsigned nreg01;            // pairs in region 0 | pairs in region 1 << 16
+    unsigned nreg2_quads;       // pairs in region 2 | count1 quads << 16
+    unsigned tabs;              // Huffman table of region 0 | region 1 << 8 | region 2 << 16 | count1 table << 24
+    int not_null;               // 0 = the segment carries no bits at all
     unsigned short sf[40];      // (length << 8) | value of each transmitted scalefactor field
 };
 // One frame: its main data spans the pending slots from first_slot on (the first one has main_bytes bytes in use)

@@ -14,7 +14,7 @@ b.encode_host(pcm)
 prof = b.debug_read("prof", np.uint64, S * 64).reshape(S, 64).astype(np.float64)
 names = {0: "load xr", 1: "startup", 2: "seek_initial", 3: "seek_actual", 4: "trade_dual", 5: "scale_factors", 6: "big_lucky",
          7: "do_quant", 8: "count_bits", 9: "increase_bits", 10: "decrease_bits", 11: "inverse_sf2", 12: "bitallo total",
-         13: "pack_huff", 14: "frame setup", 15: "compute_mask", 16: "pack_sf", 17: "flush+side", 18: "emit", 19: "sweep: post", 30: "sweep: join wait", 20: "#seek sweeps", 21: "#lucky passes", 22: "#count_bits", 23: "lucky: setup", 24: "lucky: terms", 25: "lucky: sums", 26: "lucky: replay", 27: "sweep: publish", 28: "sweep: lines", 29: "sweep: sums", 32: "startup_ms: lines", 33: "startup_ms: sums", 34: "startup_ms: NT", 35: "startup_ms: pow34", 36: "cnt: ballots", 37: "cnt: j2/j3", 38: "cnt: regions", 39: "cnt: pairs", 40: "cnt: quads", 41: "cnt: reduce", 42: "huff: build pairs", 43: "huff: place pairs", 44: "huff: build quads", 45: "huff: place quads", 31: "kernel total"}
+         13: "hand-over: records + lines", 14: "frame setup", 15: "compute_mask", 16: "next granule fetch issue", 17: "flush+side", 18: "emit", 19: "hand-over: scalefactor sizing", 30: "sweep: join wait", 20: "#seek sweeps", 21: "#lucky passes", 22: "#count_bits", 23: "lucky: setup", 24: "lucky: terms", 25: "lucky: sums", 26: "lucky: replay", 27: "sweep: publish", 28: "sweep: lines", 29: "sweep: sums", 32: "sf: scfsi", 33: "sf: maxima", 34: "sf: compress", 35: "sf: sum", 36: "cnt: ballots", 37: "cnt: j2/j3", 38: "cnt: regions", 39: "cnt: pairs", 40: "cnt: quads", 41: "cnt: reduce", 42: "huff: build pairs", 43: "huff: place pairs", 44: "huff: build quads", 45: "huff: place quads", 31: "kernel total"}
 tot = prof[:, 31].mean()
 print("mean cycles per frame (clock64 ticks), S=%d F=%d" % (S, F))
 for k in sorted(names):
