@@ -474,49 +474,132 @@ def test_golden_reference_streams(name):
     b.close()
 
 
-def test_every_stage_bit_exact():
-    """K1 polyphase, K3 MDCT, K4 psy, K5/K6 decisions and side info against oracle taps"""
-    kw = CONFIGS["cbr128"]
-    S, F = 4, 20
+STAGE_CASES = {
+    # name: (control, sample rate, bursts, what the oracle taps for this path)
+    "cbr128_long": (dict(bitrate=64, short_block_threshold=99999), 44100, False, "full"),
+    "vbr50_sw": (dict(), 44100, True, "full"),                              # block types 0 / 1 / 2 / 3, short spectra [3][192]
+    "vbr100_hf2_48k_sw": (dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), 48000, True, "full"),
+    "cbr128_lr_sw": (dict(bitrate=64, mode=0), 44100, True, "full"),        # plain stereo: the L/R start values
+    "mono_vbr50": (dict(mode=3), 44100, True, "lines"),
+    "lsf_cbr64_22k": (dict(bitrate=32, samprate=22050), 22050, True, "lines"),
+    "lsf_mono_vbr_16k": (dict(samprate=16000, mode=3), 16000, True, "lines"),
+}
+
+
+@pytest.mark.parametrize("name", list(STAGE_CASES))
+def test_every_stage_bit_exact(name):
+    """Stage by stage against the oracle's taps, bit patterns compared with == : K1 polyphase, K4 MDCT (long and
+    short layouts) and psy model, block types, K5 stereo decision, K6 side info / scalefactors / reservoir, and
+    what K6 hands to the packer (quantised lines and signs).  Mono and MPEG-2 paths: the taps the oracle has there
+    (spectrum, block types, quantised lines, signs)."""
+    kw, sr, bursts, taps = STAGE_CASES[name]
+    mono = kw.get("mode") == 3
+    S, F = 4, 24
     NG = 2 * F
-    pcm = np.stack([synth.stream_pcm(200 + i, F, rho=RHOS[i % 4]) for i in range(S)])
+    pcm = np.stack([synth.stream_pcm(200 + i, F, sr=sr, rho=RHOS[i % 4], bursts=bursts) for i in range(S)])
+    if mono:
+        pcm = pcm[:, :, 0]
     b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
     b.debug_enable(True)
     got = b.encode_host(pcm)
+    assert b.status() == 0
     sb = b.debug_read("sb", np.float32, S * 2 * (NG + 3) * 576).reshape(S, 2, NG + 3, 576)
     xr = b.debug_read("xr", np.float32, S * NG * 1152).reshape(S, NG, 2, 576)
     etab = b.debug_read("etab", np.float32, S * NG * 128).reshape(S, NG, 2, 64)
     thr = b.debug_read("thr", np.float32, S * NG * 128).reshape(S, NG, 2, 64)
+    btg = b.debug_read("bt", np.uint8, S * NG).reshape(S, NG)
+    ixq = b.debug_read("ixq", np.int16, S * NG * 1152).reshape(S, NG, 2, 576).astype(np.int32) & 0xFFFF
+    sgn = b.debug_read("sgn", np.uint8, S * NG * 1152).reshape(S, NG, 2, 576)
+    npart = np.zeros(1, np.int32)
+    assert api().lib().hx_debug_host_table(C.byref(api().default_control(**kw)), b"psy_npart", npart.ctypes.data, 4) == 4
+    np2 = int(npart[0] + 1) & ~1
 
     class GDbg(C.Structure):
         _fields_ = [("ms", C.c_int), ("ms_metric", C.c_int * 2), ("byte_pool", C.c_int), ("MNR_after", C.c_int),
                     ("mask_mb", C.c_int * 88), ("gr", C.c_int * 96), ("sf", C.c_int * 88), ("scfsi", C.c_int * 2),
                     ("main_bytes", C.c_int)]
     raw = b.debug_read("dbg", np.uint8, S * F * C.sizeof(GDbg))
+    seen_bt = set()
     for s in range(S):
         enc = O.OracleEncoder(O.default_control(**kw))
         d = O.oracle_enable_debug(enc)
         out = []
         for f in range(F):
             out.append(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]))
-            sn = np.array(d.sample_new).reshape(2, 2, 576)
             xp = np.array(d.xr_pre).reshape(2, 2, 576)
+            oix = np.array(d.ix).reshape(2, 2, 576)
+            osg = np.array(d.signx).reshape(2, 2, 576)
+            ogr = np.array(d.gr).reshape(2, 2, 27)
+            gd = GDbg.from_buffer_copy(raw[(s * F + f) * C.sizeof(GDbg):(s * F + f + 1) * C.sizeof(GDbg)].tobytes())
+            ggr = np.array(gd.gr).reshape(2, 2, 24)
+            for igr in range(2):
+                g = 2 * f + igr
+                bt = int(d.block_type[igr])
+                seen_bt.add(bt)
+                assert btg[s, g] == bt, ("block type", s, f, igr)
+                for ch in range(1 if mono else 2):
+                    assert np.array_equal(bits(xr[s, g, ch]), bits(xp[igr, ch])), ("mdct", s, f, igr, ch, bt)
+                    # what K6 hands to k_pack: the quantised lines of the coded range and the signs of the non-zero ones
+                    n = 2 * int(ggr[igr, ch, 1]) + 4 * max(int(ggr[igr, ch, 18]), 0) if ggr[igr, ch, 20] else 0
+                    assert np.array_equal(ixq[s, g, ch, :n], oix[igr, ch, :n]), ("ix", s, f, igr, ch, bt)
+                    nz = oix[igr, ch, :n] != 0
+                    assert np.array_equal(sgn[s, g, ch, :n][nz], osg[igr, ch, :n][nz]), ("signs", s, f, igr, ch, bt)
+                    assert np.array_equal(ggr[igr, ch], ogr[igr, ch, :24]), ("side info", s, f, igr, ch, bt)
+            if taps != "full":
+                continue
+            sn = np.array(d.sample_new).reshape(2, 2, 576)
             oe = np.array(d.etab).reshape(2, 2, 64)
             ot = np.array(d.thr).reshape(2, 2, 64)
             for igr in range(2):
+                g = 2 * f + igr
                 for ch in range(2):
-                    g = 2 * f + igr
                     assert np.array_equal(bits(sb[s, ch, 3 + g]), bits(sn[igr, ch])), ("polyphase", s, f, igr, ch)
-                    assert np.array_equal(bits(xr[s, g, ch]), bits(xp[igr, ch])), ("mdct", s, f, igr, ch)
-                    assert np.array_equal(bits(etab[s, g, ch, :42]), bits(oe[igr, ch, :42])), ("etab", s, f, igr, ch)
-                    assert np.array_equal(bits(thr[s, g, ch, :42]), bits(ot[igr, ch, :42])), ("thr", s, f, igr, ch)
-            gd = GDbg.from_buffer_copy(raw[(s * F + f) * C.sizeof(GDbg):(s * F + f + 1) * C.sizeof(GDbg)].tobytes())
+                    if d.block_type[igr] != 2:      # (the oracle taps the long model's partition tables)
+                        assert np.array_equal(bits(etab[s, g, ch, :np2]), bits(oe[igr, ch, :np2])), ("etab", s, f, igr, ch)
+                        assert np.array_equal(bits(thr[s, g, ch, :np2]), bits(ot[igr, ch, :np2])), ("thr", s, f, igr, ch)
             assert gd.ms == d.ms and list(gd.ms_metric) == list(d.ms_metric)
             assert gd.byte_pool == d.byte_pool and gd.MNR_after == d.MNR_after and gd.main_bytes == d.main_bytes
-            assert np.array_equal(np.array(gd.gr), np.array(d.gr).reshape(2, 2, 27)[:, :, :24].reshape(-1))
-            assert np.array_equal(np.array(gd.sf), np.array(d.sf))
-            assert list(gd.scfsi) == list(d.scfsi)
+            if d.block_type[0] != 2 and d.block_type[1] != 2:
+                assert np.array_equal(np.array(gd.sf), np.array(d.sf))
+                assert list(gd.scfsi) == list(d.scfsi)
         assert got[s] == b"".join(out)
+    if bursts and "long" not in name:
+        assert {0, 1, 2, 3} <= seen_bt, seen_bt      # every block type went through the stage comparison
+    b.close()
+
+
+@pytest.mark.parametrize("cfg", ["config3", "config5_share"])
+def test_full_batch_configs_3_and_5(cfg):
+    """BASELINE configs 3 (4096 streams, VBR -V50, block switching) and one GPU's share of config 5 (4096 streams,
+    32 / 44.1 / 48 kHz by stream, CBR-128, correlation cycled) at full batch width with 256 distinct signals:
+    frame structure of every stream, and byte equality with the oracle on a 16-stream subset."""
+    a = api()
+    S, F = 4096, 32
+    U = 256 if cfg == "config3" else 252        # distinct signals; a multiple of the class count (3) and of the correlation cycle (4)
+    if cfg == "config3":
+        classes = [(dict(), 44100)]
+    else:
+        classes = [(dict(bitrate=64, samprate=32000), 32000), (dict(bitrate=64), 44100), (dict(bitrate=64, samprate=48000), 48000)]
+    base = [synth.stream_pcm(9000 + u, F, sr=classes[u % len(classes)][1], rho=RHOS[u % 4], bursts=True) for u in range(U)]
+    # stream i carries signal i mod U, rotated in time for the later copies
+    pcm = np.stack([np.roll(base[i % U], 1152 * 3 * (i // U), axis=0) for i in range(S)])
+    ctl = [a.default_control(**classes[(i % U) % len(classes)][0]) for i in range(S)]
+    b = a.Batch(ctl if len(classes) > 1 else ctl[0], nstreams=S, max_frames=F)
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    rng = np.random.Generator(np.random.PCG64(11))
+    for s in rng.choice(S, 16, replace=False):
+        assert got[s] == oracle_bytes(classes[(s % U) % len(classes)][0], pcm[s], F), "stream %d" % s
+    for s in range(0, S, 61):       # every frame starts with a sync word and the sizes add up
+        bs, pos, n = got[s], 0, 0
+        kw, sr = classes[(s % U) % len(classes)]
+        while pos < len(bs):
+            assert bs[pos] == 0xFF and (bs[pos + 1] & 0xFE) == 0xFA
+            br = [0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320][bs[pos + 2] >> 4]
+            pos += 144000 * br // sr + ((bs[pos + 2] >> 1) & 1)
+            n += 1
+        assert pos == len(bs) and F - 6 <= n <= F
+    assert len(set(got[:U])) == U       # distinct signals give distinct streams
     b.close()
 
 
