@@ -13,9 +13,9 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this
  * library.  The product (hmp3_amd/) never includes, links or calls anything here.
  *
- * Scope: MPEG-1 (32/44.1/48 kHz), stereo (mode 0) and joint stereo (mode 1) without
- * intensity stereo (i.e. CBR >= 48 kbps/ch or VBR), long and short blocks, CBR and VBR,
- * -HF high-frequency extension.  Mono, MPEG-2, intensity stereo: hxo_init returns 0.
+ * Scope: MPEG-1 (32/44.1/48 kHz) and MPEG-2 LSF (16/22.05/24 kHz); stereo, joint stereo (with
+ * intensity coding at the low bitrates), dual channel and mono; long and short blocks, CBR and
+ * VBR, -HF high-frequency extension.
  */
 #ifndef HXO_H
 #define HXO_H
@@ -65,7 +65,9 @@ typedef struct {
     int nband, nsb, nsb_limit, nsb_limitMS[2], band_limit, band_limit_stereo;
     int framebytes, remainder, divisor, main_framebytes, side_bytes, sf_bit_max, AveTargetBits;
     int ms_flag, hf_flag, vbr_flag, short_block_threshold, filter_dc;
-    int nchan;                  /* 1 = mono (mode 3), 2 = stereo / joint stereo */
+    int nchan;                  /* 1 = mono (mode 3), 2 = stereo / joint stereo / dual channel */
+    int is_flag;                /* joint stereo with an intensity part (nsf[1] < nsf[0]) */
+    int alloc1;                 /* 1: the first-generation allocator (CBitAllo1) codes this stream: intensity stereo or dual channel */
     int h_id;                   /* 1 = MPEG-1 (32 / 44.1 / 48 kHz), 0 = MPEG-2 LSF (16 / 22.05 / 24 kHz): one granule per frame */
     int tix;                    /* row of the band tables: h_sr_index + 3 * (1 - h_id) */
     float filter_alpha;
@@ -89,6 +91,20 @@ typedef struct {
     /* short-block allocator init (bitallos.cpp:128-200) */
     int nsfs, nbmax_s, look_log_cbwmb_s[16];
 } hxo_params;
+
+/* carried state of the first-generation allocator (pub/bitallo1.h:80-140) */
+typedef struct {
+    int call_count, bitadjust, bitadjust_save[2];
+    int gsf[2][21], gsf_save[2][21], sf[2][21];
+    float running_a, ave_alpha_nmr, alpha_nmr;
+} hxo_a1;
+/* its tables (bitallo1.cpp:107-211, 444-543) */
+typedef struct {
+    int nsf[2], nBand[21], startBand[22], ill_is_pos;
+    float look_log_cbw[21], look_f_ixmax[256], look_f_ix[256], look_f_big_ixmax[256], look_f_big_ix[256];
+    int look_bits[256], look_is_pos[34];
+    float gz_con0, gz_con1, gz_con2, con707, Ssb[21];
+} hxo_a1tab;
 
 typedef struct {
     /* input filter + polyphase history (filter2.c, pub/mp3enc.h:241-243) */
@@ -115,6 +131,7 @@ typedef struct {
     int hf_quant, hf_quant_stereo[2], gsf_hf, gsf_hf_stereo[2];
     /* short-block allocator carried state */
     int s_call_count;
+    hxo_a1 a1;
     /* bit reservoir / frame assembly (mp3enc.cpp:2230-2333) */
     int padcount;
     unsigned main_tot, main_sent, mf_tot;
@@ -150,6 +167,7 @@ typedef struct {
 typedef struct hxo_encoder {
     hxo_params p;
     hxo_state s;
+    hxo_a1tab a1t;
     hxo_frame_debug *dbg;
     unsigned char *packet;      /* set for the duration of hxo_encode_frame_packet */
     int packet_bytes, packet_bytes2[2];    /* MPEG-2: two packets per call, back to back */

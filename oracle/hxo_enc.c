@@ -115,7 +115,6 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     if (sr_all[k] == 1) return 0;
     p->h_id = h_id;
     p->tix = p->h_sr_index + 3 * (1 - h_id);
-    if (ec.mode == 2) return 0;             /* dual channel (CBitAllo1): out of scope */
     p->h_mode = ec.mode;
     p->nchan = (ec.mode == 3) ? 1 : 2;
     mode_ext = 0;
@@ -256,7 +255,9 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
         if (nsbstereo_limit < p->nsb_limit) is_flag = 1;
         p->ms_flag = 1;
     }
-    if (is_flag) return 0;                  /* intensity stereo (CBitAllo1): out of scope */
+    p->is_flag = is_flag;
+    p->alloc1 = is_flag || p->h_mode == 2;  /* mp3enc.cpp:696-766: the first-generation allocator codes these */
+    if (is_flag) ec.vbr_flag = 0;
     p->vbr_flag = ec.vbr_flag;
     if (ec.vbr_flag) gen_vbr_table(p, (ec.mode == 3 ? 1 : 2) * ec.vbr_br_limit);
     if (ec.vbr_flag) {
@@ -315,6 +316,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     s->gsf_hf = -1;
     s->gsf_hf_stereo[0] = s->gsf_hf_stereo[1] = -1;
     hxo_short_init(e);
+    if (p->alloc1) hxo_a1_init(e);
 
     /* stream state (mp3enc.cpp:278-287,788-837) */
     for (i = 0; i < 32; i++) s->attack_buf[0][i] = s->attack_buf[1][i] = 9000;
@@ -328,7 +330,7 @@ int hxo_init(hxo_encoder *e, const hxo_control *ec_arg)
     p->ec.bitrate = p->totbitrate;
     if (p->h_mode != 3) p->ec.bitrate /= 2;
     p->ec.samprate = p->samprate;
-    p->ec.nsbstereo = 32;
+    p->ec.nsbstereo = is_flag ? nsbstereo : 32;
     p->ec.freq_limit = ec.hf_flag ? ec.freq_limit : p->nsb_limit * (p->samprate / 64);
     p->ec.nsb_limit = p->nsb_limit;
     p->ec.layer = 3;
@@ -555,6 +557,171 @@ static int encode_single(hxo_encoder *e, hxo_bitw *w)
     return 0;
 }
 
+/* ---- streams coded by the first-generation allocator: long blocks only, no block-type decision ---- */
+static void psy_long_all(hxo_encoder *e, int igr)
+{
+    int ch;
+    for (ch = 0; ch < e->p.nchan; ch++) hxo_psy_long(&e->p, e->s.xr[igr][ch], e->s.ecsave[ch], e->s.sig_mask[ch], 0);
+}
+
+/* encode_jointA (mp3enc.cpp:1236-1318): joint stereo with an intensity part, both channels allocated together */
+static int encode_joint_a1(hxo_encoder *e, hxo_bitw *w)
+{
+    hxo_state *s = &e->s;
+    const hxo_params *p = &e->p;
+    int ch, igr, bits, ba_bit_min, ba_bit_max, ba_min, ba_max, TargetBits, sf_bits, ms = 0;
+    TargetBits = p->AveTargetBits + p->AveTargetBits;
+    ba_bit_max = s->byte_max << 2;
+    if (ba_bit_max > 4095) ba_bit_max = 4095;
+    ba_bit_min = s->byte_min << 2;
+    sf_bits = p->sf_bit_max + p->sf_bit_max;
+    ba_bit_max -= sf_bits;
+    ba_bit_min -= sf_bits;
+    ba_min = ba_bit_min;
+    ba_max = ba_bit_max;
+    transform_granule(e, 0);
+    transform_granule(e, 1);
+    if (p->ms_flag) {
+        int m1 = hxo_a1_ms_metric(e, (const float (*)[576]) s->xr[0]), m2 = hxo_a1_ms_metric(e, (const float (*)[576]) s->xr[1]);
+        s->last_ms_metric[0] = m1; s->last_ms_metric[1] = m2;
+        if ((m1 + m2) >= 0) ms = 1;
+    }
+    if (e->dbg) {
+        e->dbg->ms = ms; e->dbg->ms_metric[0] = s->last_ms_metric[0]; e->dbg->ms_metric[1] = s->last_ms_metric[1];
+        e->dbg->byte_pool = s->byte_pool;
+        memcpy(e->dbg->xr_pre, s->xr, sizeof(s->xr));
+        e->dbg->block_type[0] = e->dbg->block_type[1] = 0;
+    }
+    for (igr = 0; igr < 2; igr++) {
+        psy_long_all(e, igr);
+        hxo_bitallo1(e, s->xr[igr], s->sig_mask, 0, 2, ba_min, TargetBits, ba_max, s->sf[igr], s->gr[igr], s->ix, s->signx, ms);
+        if (e->dbg) {
+            memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
+            memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+        }
+        for (ch = 0; ch < 2; ch++) {
+            hxo_gr *g = &s->gr[igr][ch];
+            bits = 0;
+            g->scalefac_compress = hxo_pack_sf_long_scfsi(w, s->sf_save[ch], &s->sf[igr][ch], igr, &s->scfsi[ch], g->aux_not_null);
+            if (g->aux_not_null) bits = hxo_pack_huff(w, g, s->ix[ch], s->signx[ch]);
+            ba_min -= bits;
+            ba_max -= bits;
+            g->part2_3_length = bits;
+        }
+        ba_min += ba_bit_min + sf_bits;
+        ba_max += ba_bit_max + sf_bits;
+    }
+    return ms;
+}
+
+/* encode_singleA (mp3enc.cpp:1601-1672): dual channel, each channel allocated on its own */
+static int encode_single_a1(hxo_encoder *e, hxo_bitw *w)
+{
+    hxo_state *s = &e->s;
+    const hxo_params *p = &e->p;
+    int ch, igr, bits, ba_bit_min, ba_bit_max, ba_min, ba_max;
+    ba_bit_max = s->byte_max << 1;          /* two channels share the frame */
+    ba_bit_min = s->byte_min << 1;
+    if (ba_bit_max > 4095) ba_bit_max = 4095;
+    ba_bit_max -= p->sf_bit_max;
+    ba_bit_min -= p->sf_bit_max;
+    ba_min = ba_bit_min;
+    ba_max = ba_bit_max;
+    transform_granule(e, 0);
+    transform_granule(e, 1);
+    if (e->dbg) {
+        e->dbg->ms = 0; e->dbg->ms_metric[0] = e->dbg->ms_metric[1] = 0;
+        e->dbg->byte_pool = s->byte_pool;
+        memcpy(e->dbg->xr_pre, s->xr, sizeof(s->xr));
+        e->dbg->block_type[0] = e->dbg->block_type[1] = 0;
+    }
+    for (igr = 0; igr < 2; igr++) {
+        psy_long_all(e, igr);
+        for (ch = 0; ch < 2; ch++) {
+            hxo_gr *g = &s->gr[igr][ch];
+            hxo_bitallo1(e, s->xr[igr] + ch, s->sig_mask + ch, ch, 1, ba_min, p->AveTargetBits, ba_max, &s->sf[igr][ch], g,
+                         s->ix + ch, s->signx + ch, p->ms_flag);
+            bits = 0;
+            g->scalefac_compress = 0;
+            if (g->aux_bits) {
+                g->scalefac_compress = hxo_pack_sf_long(w, &s->sf[igr][ch]);
+                bits = hxo_pack_huff(w, g, s->ix[ch], s->signx[ch]);
+            }
+            ba_min += ba_bit_min + p->sf_bit_max - bits;
+            ba_max += ba_bit_max + p->sf_bit_max - bits;
+            g->part2_3_length = bits;
+        }
+        if (e->dbg) {
+            memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
+            memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+        }
+    }
+    s->scfsi[0] = s->scfsi[1] = 0;
+    return 0;
+}
+
+/* encode_jointA_MPEG2 (mp3enc.cpp:1753-1829) and encode_singleA_MPEG2 (:1910-1973): one granule = one frame */
+static int encode_granule_lsf_a1(hxo_encoder *e, hxo_bitw *w, int igr)
+{
+    hxo_state *s = &e->s;
+    const hxo_params *p = &e->p;
+    int ch, bits, bit_min, bit_max, ba_min, ba_max, ms = 0;
+    if (p->h_mode == 2) {
+        bit_max = s->byte_max << 2;
+        bit_min = s->byte_min << 2;
+        ba_max = HXO_MIN(bit_max, 4095) - p->sf_bit_max;
+        ba_min = bit_min - p->sf_bit_max;
+        transform_granule(e, igr);
+        if (e->dbg) { e->dbg->ms = 0; e->dbg->byte_pool = s->byte_pool; e->dbg->block_type[igr] = 0; memcpy(e->dbg->xr_pre[igr], s->xr[igr], sizeof(s->xr[igr])); }
+        psy_long_all(e, igr);
+        for (ch = 0; ch < 2; ch++) {
+            hxo_gr *g = &s->gr[igr][ch];
+            const int ba_bit_max = HXO_MIN(bit_max, 4095) - p->sf_bit_max, ba_bit_min = bit_min - p->sf_bit_max;
+            hxo_bitallo1(e, s->xr[igr] + ch, s->sig_mask + ch, ch, 1, ba_min, p->AveTargetBits, ba_max, &s->sf[igr][ch], g,
+                         s->ix + ch, s->signx + ch, p->ms_flag);
+            bits = 0;
+            g->scalefac_compress = 0;
+            if (g->aux_bits) {
+                g->scalefac_compress = hxo_pack_sf_lsf(w, &s->sf[igr][ch], 0);
+                bits = hxo_pack_huff(w, g, s->ix[ch], s->signx[ch]);
+            }
+            ba_min += ba_bit_min + p->sf_bit_max - bits;
+            ba_max += ba_bit_max + p->sf_bit_max - bits;
+            g->part2_3_length = bits;
+        }
+        if (e->dbg) { memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix)); memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx)); }
+        return 0;
+    }
+    bit_max = s->byte_max << 3;
+    bit_min = s->byte_min << 3;
+    if (s->byte_pool > 245) bit_min += 40;
+    ba_max = HXO_MIN(bit_max, 4095) - 2 * p->sf_bit_max;
+    ba_min = bit_min - 2 * p->sf_bit_max;
+    transform_granule(e, igr);
+    if (p->ms_flag) {
+        int m1 = hxo_a1_ms_metric(e, (const float (*)[576]) s->xr[igr]);
+        s->last_ms_metric[igr] = m1;
+        if (m1 >= 0) ms = 1;
+    }
+    if (e->dbg) { e->dbg->ms = ms; e->dbg->byte_pool = s->byte_pool; e->dbg->block_type[igr] = 0; memcpy(e->dbg->xr_pre[igr], s->xr[igr], sizeof(s->xr[igr])); }
+    psy_long_all(e, igr);
+    hxo_bitallo1(e, s->xr[igr], s->sig_mask, 0, 2, ba_min, p->AveTargetBits + p->AveTargetBits, ba_max, s->sf[igr], s->gr[igr],
+                 s->ix, s->signx, ms);
+    if (e->dbg) { memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix)); memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx)); }
+    for (ch = 0; ch < 2; ch++) {
+        hxo_gr *g = &s->gr[igr][ch];
+        bits = 0;
+        g->scalefac_compress = 0;
+        if (g->aux_not_null) {
+            if (ch & p->is_flag) g->scalefac_compress = hxo_pack_sf_lsf_is(w, &s->sf[igr][ch], e->a1t.nsf[1]);
+            else g->scalefac_compress = hxo_pack_sf_lsf(w, &s->sf[igr][ch], 0);
+            bits = hxo_pack_huff(w, g, s->ix[ch], s->signx[ch]);
+        }
+        g->part2_3_length = bits;
+    }
+    return ms;
+}
+
 /* encode_jointB_MPEG2 (mp3enc.cpp:1832-1907) and encode_singleB_MPEG2 (:1977-2027): one granule = one frame */
 static int encode_granule_lsf(hxo_encoder *e, hxo_bitw *w, int igr)
 {
@@ -638,9 +805,9 @@ static int encode_block_lsf(hxo_encoder *e, unsigned char *out)
             s->byte_min = p->vbr_main_framebytes[p->ivbr_min] + s->byte_pool - 255;
         }
         hxo_bw_init(&w, s->main_buf + s->main_p1);
-        ms = encode_granule_lsf(e, &w, igr);
+        ms = p->alloc1 ? encode_granule_lsf_a1(e, &w, igr) : encode_granule_lsf(e, &w, igr);
         s->last_ms = ms;
-        s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms);
+        s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms + p->is_flag);
         bytes = hxo_bw_flush(&w);
         assert(bytes <= s->byte_max);
         if (e->dbg) {
@@ -671,7 +838,7 @@ static int encode_block_lsf(hxo_encoder *e, unsigned char *out)
         if (pk) {       /* mp3enc.cpp:3352-3362, :3196-3206: the two packets back to back */
             pk[0] = p->head[0]; pk[1] = p->head[1]; pk[2] = p->head[2]; pk[3] = p->head[3];
             if (pad) pk[2] |= 2;
-            pk[3] = (unsigned char) ((pk[3] & 0xCF) | ((ms + ms) << 4));
+            pk[3] = (unsigned char) ((pk[3] & 0xCF) | ((ms + ms + p->is_flag) << 4));
             memcpy(pk + 4, s->side_buf[s->side_p1], p->side_bytes);
             memcpy(pk + 4 + p->side_bytes, s->main_buf + s->main_p1, (size_t) raw_bytes);
             e->packet_bytes2[igr] = 4 + p->side_bytes + raw_bytes;
@@ -744,9 +911,10 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         s->byte_min = p->vbr_main_framebytes[p->ivbr_min] + s->byte_pool - 511;
     }
     hxo_bw_init(&w, s->main_buf + s->main_p1);
-    ms = (p->nchan == 2) ? encode_joint(e, &w) : encode_single(e, &w);
+    if (p->alloc1) ms = (p->h_mode == 2) ? encode_single_a1(e, &w) : encode_joint_a1(e, &w);
+    else ms = (p->nchan == 2) ? encode_joint(e, &w) : encode_single(e, &w);
     s->last_ms = ms;
-    s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms);
+    s->mode_ext_buf[s->side_p1] = (unsigned char) (ms + ms + p->is_flag);
     bytes = hxo_bw_flush(&w);
     assert(bytes <= s->byte_max);
     if (e->dbg) {
@@ -774,7 +942,7 @@ int hxo_encode_frame(hxo_encoder *e, const float *pcm, unsigned char *out)
         unsigned char *q = e->packet;
         q[0] = p->head[0]; q[1] = p->head[1]; q[2] = p->head[2]; q[3] = p->head[3];
         if (pad) q[2] |= 2;     /* L3_pack_head in both variants: the VBR packet keeps the nominal bitrate index */
-        q[3] = (unsigned char) ((q[3] & 0xCF) | ((ms + ms) << 4));
+        q[3] = (unsigned char) ((q[3] & 0xCF) | ((ms + ms + p->is_flag) << 4));
         memcpy(q + 4, s->side_buf[s->side_p1], p->side_bytes);
         memcpy(q + 4 + p->side_bytes, s->main_buf + s->main_p1, (size_t) raw_bytes);
         e->packet_bytes = 4 + p->side_bytes + raw_bytes;

@@ -326,6 +326,31 @@ int hxo_pack_sf_lsf(hxo_bitw *w, const hxo_scalefact *sf, int block_type)
     return slen[3] + (slen[2] << 2) + ((slen[1] + 5 * slen[0]) << 4);
 }
 
+/* l3pack.c:561-729, the intensity branch (long blocks): the right channel of an MPEG-2 joint-stereo frame with
+   intensity coding.  Three groups of 7 bands; bands from nsf_stereo on carry intensity positions, and a
+   scalefactor of 999 marks "no intensity" and is sent as the group's all-ones value (which a real position must
+   therefore never take: the group's length grows by a bit if it would).  Rewrites the 999 entries of sf. */
+int hxo_pack_sf_lsf_is(hxo_bitw *w, hxo_scalefact *sf, int nsf_stereo)
+{
+    static const int edge[4] = {0, 7, 14, 21}, cap[3] = {4, 4, 3};
+    int g, i, m[3] = {0, 0, 0}, ism[3] = {-1, -1, -1}, ip[3] = {0, 0, 0}, slen[3];
+    w->bit_pos_start = bw_pos(w);
+    for (g = 0; g < 3; g++)
+        for (i = edge[g]; i < edge[g + 1]; i++) {
+            if (sf->l[i] >= 999) { ip[g] = 1; continue; }
+            if (sf->l[i] > m[g]) m[g] = sf->l[i];
+            if (g > 0 && i >= nsf_stereo && sf->l[i] > ism[g]) ism[g] = sf->l[i];
+        }
+    for (g = 0; g < 3; g++) slen[g] = lsf_slen(m[g], cap[g]);
+    if (ism[1] == ((1 << slen[1]) - 1)) slen[1]++;
+    if (ism[2] == ((1 << slen[2]) - 1)) slen[2]++;
+    for (g = 0; g < 3; g++)
+        if (ip[g]) for (i = edge[g]; i < edge[g + 1]; i++) if (sf->l[i] >= 999) sf->l[i] = (1 << slen[g]) - 1;
+    for (g = 0; g < 3; g++) for (i = edge[g]; i < edge[g + 1]; i++) hxo_bw_put(w, sf->l[i], slen[g]);
+    g = slen[2] + 6 * slen[1] + 36 * slen[0];
+    return g + g + 1;
+}
+
 /* l3pack.c:421-558: long blocks with scfsi reuse between granule 0 and 1 */
 int hxo_pack_sf_long_scfsi(hxo_bitw *w, int sf_save[21], const hxo_scalefact *sf, int igr,
                            int *pscfsi, int not_null)

@@ -39,4 +39,12 @@ int hxo_bitallo_short(hxo_encoder *e, float xr[2][576], hxo_sigmask sm[2][36],
                       int min_bits, int target_bits, int max_bits, int bit_pool,
                       hxo_scalefact sf_out[2], hxo_gr gr[2], int ms_flag, int MNR);
 void hxo_short_init(hxo_encoder *e);
+
+/* first-generation allocator (hxo_alloc1.c) */
+void hxo_a1_init(hxo_encoder *e);
+int hxo_a1_ms_metric(hxo_encoder *e, const float x[2][576]);
+void hxo_bitallo1(hxo_encoder *e, float xr[][576], hxo_sigmask sm[][36], int ch_arg, int nchan_arg,
+                  int min_bits, int target_bits, int max_bits, hxo_scalefact sf_out[], hxo_gr gr[],
+                  int ix[][576], unsigned char signx[][576], int ms_flag);
+int hxo_pack_sf_lsf_is(hxo_bitw *w, hxo_scalefact *sf, int nsf_stereo);
 #endif

@@ -212,3 +212,48 @@ def test_random_configurations_byte_identical():
             break
     assert done == 60
 
+
+
+A1_CASES = [
+    # streams the reference codes with its first-generation allocator (CBitAllo1): intensity stereo, dual channel
+    # (at the MPEG-1 rates CBR below 48 kbps per channel is rejected, mp3enc.cpp:346-351, and from 96 kbps total
+    # on no intensity is used: there it only happens on request, E_CONTROL nsbstereo / -N)
+    ("is_n8_cbr128_44k", dict(bitrate=64, nsbstereo=8), 44100, 0.7),
+    ("is_n4_cbr96_48k", dict(bitrate=48, nsbstereo=4, samprate=48000), 48000, 0.3),
+    ("is_n12_cbr112_32k", dict(bitrate=56, nsbstereo=12, samprate=32000), 32000, 0.0),
+    ("is_n3_cbr128_44k_rho1", dict(bitrate=64, nsbstereo=3), 44100, 1.0),
+    ("is_n16_cbr192_44k", dict(bitrate=96, nsbstereo=16), 44100, 0.7),
+    ("dual_cbr128", dict(bitrate=64, mode=2), 44100, 0.0),
+    ("dual_cbr96_48k", dict(bitrate=48, mode=2, samprate=48000), 48000, 0.7),
+    ("lsf_is_cbr32_22k", dict(bitrate=16, samprate=22050), 22050, 0.7),
+    ("lsf_is_cbr16_16k", dict(bitrate=8, samprate=16000), 16000, 0.3),
+    ("lsf_is_cbr40_24k", dict(bitrate=20, samprate=24000), 24000, 0.0),
+    ("lsf_dual_cbr64_22k", dict(bitrate=32, samprate=22050, mode=2), 22050, 0.3),
+    ("lsf_dual_cbr32_16k", dict(bitrate=16, samprate=16000, mode=2), 16000, 0.7),
+]
+
+
+@pytest.mark.parametrize("name,kw,sr,rho", A1_CASES, ids=[c[0] for c in A1_CASES])
+def test_first_generation_allocator_streams_byte_identical(name, kw, sr, rho):
+    nfr = 120
+    pcm = synth.stream_pcm(41, nfr, sr=sr, rho=rho, bursts=True)
+    r, o = O.RefEncoder(O.default_control(**kw)), O.OracleEncoder(O.default_control(**kw))
+    assert r.bytes_in != 0 and o.bytes_in != 0
+    a = O.encode_stream(r, pcm)
+    b = O.encode_stream(o, pcm)
+    assert len(a) > 0 and a == b
+
+
+def test_first_generation_allocator_stress_signals():
+    n = 30 * 1152
+    rng = np.random.default_rng(99)
+    t = np.arange(n)
+    noise = rng.integers(-32768, 32768, (n, 2)).astype(np.int16)
+    tone = np.round(32767 * np.sin(2 * np.pi * 110.0 * t / 44100.0)).astype(np.int16)
+    silence = np.zeros((n, 2), np.int16)
+    quiet = (noise // 4096).astype(np.int16)
+    for kw in (dict(bitrate=64, nsbstereo=6), dict(bitrate=64, mode=2), dict(bitrate=16, samprate=22050)):
+        for pcm in (noise, np.stack([tone, tone], axis=1), silence, quiet, np.stack([tone, -tone], axis=1)):
+            a = O.encode_stream(O.RefEncoder(O.default_control(**kw)), pcm)
+            b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+            assert a == b, kw
