@@ -19,6 +19,9 @@
 #ifndef HX_LSF
 #define HX_LSF 0            // 1 when compiled as hx_alloc_lsf.hip: MPEG-2 LSF streams, one granule per frame
 #endif
+#ifndef HX_A1
+#define HX_A1 0             // 1 when compiled as hx_alloc1*.hip: streams of the first-generation allocator (intensity stereo, dual channel)
+#endif
 #define GMIN_OFFSET 70
 #define PART23 4021
 #define NB 22
@@ -37,6 +40,7 @@ struct AllocPrm {
     int nsfs, nbmax_s;
     struct { int npart; } psyS;
     int nchan, side_bytes;              // 1 / 17 for a mono stream (mode 3), 2 / 32 otherwise
+    int is_flag, dual, npart_l;         // first-generation allocator: intensity part present, dual channel; long psy partitions
     int oflags;                         // optional outputs of the call: 1 = packets, 2 = debug taps, 4 = per-frame counters
 };
 
@@ -70,6 +74,11 @@ struct alignas(16) AllocLds {
             float gig[2][NB], gg[2][NB];        // gain pair of the band's current evaluation step
             int lucky[6][2][13];                // big_lucky_noise: noise of candidate c of band (ch, sfb)
         };
+        struct {    // first-generation allocator (hx_alloc1.inc): psy model output and noise / mask levels per band in dB
+            int a_pad[17][2][NB];       // (the long-block arrays up to x34max stay in use)
+            float a_sig[2][NB], a_smask[2][NB], a_mask[2][NB], a_noise[2][NB];
+            int a_lastGsf[2][NB];
+        };
         struct {    // short blocks: [channel][window][sfb]
             int s_snr[2][3][16], s_Noise0[2][3][16], s_Noise[2][3][16], s_NT[2][3][16];
             int s_gzero[2][3][16], s_gmin[2][3][16], s_gsf[2][3][16], s_sf[2][3][16], s_active[2][3][16];
@@ -83,6 +92,8 @@ struct alignas(16) AllocLds {
     int hs_table[2][4], hs_cbreg[2][3], hs_nbig[2], hs_nquads[2], hs_bits[2];
     // stream scalars (persist across frames)
     int MNR, PoolFraction, call_count;
+    int a_calls, a_bitadjust[2];        // first-generation allocator's carried scalars
+    float a_running, a_ave, a_alpha;
     int hf_quant, hf_quant_stereo[2], gsf_hf, gsf_hf_stereo[2];
     int sf_save[2][21];
     int scfsi[2];
@@ -1058,4 +1069,7 @@ __device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
 
 #include "hx_alloc2.inc"
 #include "hx_alloc_short.inc"
+#if HX_A1
+#include "hx_alloc1.inc"
+#endif
 #include "hx_alloc3.inc"

@@ -35,6 +35,8 @@ __global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long o
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
+__global__ void k_alloc1(AllocArgs a);
+__global__ void k_alloc1_lsf(AllocArgs a);
 
 static thread_local std::string g_err;
 static void set_err(const char *fmt, const char *a = "")
@@ -74,6 +76,7 @@ struct hx_batch {
     bool any_dc = false;
     int nchan = 2;                      // channels of the PCM input, the same for every stream of the batch
     int lsf = 0;                        // 1: an MPEG-2 LSF batch (16 / 22.05 / 24 kHz): every 1152-sample block yields two frames
+    int alloc1 = 0;                     // 1: streams of the first-generation allocator (intensity stereo, dual channel): k_alloc1*
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
     unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
     HxFrameDebug *d_dbg = nullptr;
@@ -180,9 +183,10 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         for (size_t i = 0; i < seen.size(); i++) if (memcmp(&seen[i], c, sizeof(HxControl)) == 0) { k = (int) i; break; }
         if (k < 0) {
             HxParams p;
-            if (!hx_resolve(c, &p)) { set_err("configuration rejected (see hx_resolve: mono / stereo / joint stereo without intensity only)"); delete b; return nullptr; }
+            if (!hx_resolve(c, &p)) { set_err("configuration rejected (the reference's L3_audio_encode_init returns 0 for it)"); delete b; return nullptr; }
             if (p.filter_dc) b->any_dc = true;
-            if (b->params.empty()) { b->nchan = p.nchan; b->lsf = p.h_id ? 0 : 1; }
+            if (b->params.empty()) { b->nchan = p.nchan; b->lsf = p.h_id ? 0 : 1; b->alloc1 = p.alloc1; }
+            else if (p.alloc1 != b->alloc1) { set_err("intensity-stereo / dual-channel streams (first-generation allocator) cannot share a batch with the others"); delete b; return nullptr; }
             else if (p.nchan != b->nchan) { set_err("mono and stereo streams cannot share a batch (the PCM layout differs)"); delete b; return nullptr; }
             else if ((p.h_id ? 0 : 1) != b->lsf) { set_err("MPEG-1 and MPEG-2 sample rates cannot share a batch (frames per call differ)"); delete b; return nullptr; }
             seen.push_back(*c);
@@ -229,7 +233,8 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         hipDeviceProp_t prop;
         int per_cu = 0;
         HIPCHKN(hipGetDeviceProperties(&prop, device));
-        if ((b->lsf ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_alloc_lsf, 128, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_alloc, 128, 0)) != hipSuccess || per_cu <= 0) per_cu = 4;
+        const void *kern = b->alloc1 ? (b->lsf ? (const void *) k_alloc1_lsf : (const void *) k_alloc1) : (b->lsf ? (const void *) k_alloc_lsf : (const void *) k_alloc);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 128, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
         b->resident = per_cu * prop.multiProcessorCount;
     }
     if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 1152 * b->nchan);
@@ -252,7 +257,7 @@ extern "C" int hx_batch_nstreams(const hx_batch *b) { return b ? b->S : 0; }
 // refused instead of silently yielding a corrupt bitstream.
 struct HxStateHeader { unsigned magic, version, state_bytes, pad; unsigned long long cfg; };
 #define HX_STATE_MAGIC 0x53335848u      // "HX3S"
-#define HX_STATE_VERSION 2u
+#define HX_STATE_VERSION 3u
 static unsigned long long cfg_fingerprint(const HxParams &p)
 {
     unsigned long long h = 1469598103934665603ull;      // FNV-1a over the echoed control and the derived frame constants
@@ -466,7 +471,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, qa));
-    if (b->lsf) LAUNCH(k_alloc_lsf, dim3(S), dim3(128), qa, a);
+    if (b->alloc1) { if (b->lsf) LAUNCH(k_alloc1_lsf, dim3(S), dim3(128), qa, a); else LAUNCH(k_alloc1, dim3(S), dim3(128), qa, a); }
+    else if (b->lsf) LAUNCH(k_alloc_lsf, dim3(S), dim3(128), qa, a);
     else LAUNCH(k_alloc, dim3(S), dim3(128), qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});

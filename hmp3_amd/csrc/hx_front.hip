@@ -452,6 +452,24 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
         if (lane == 0) *out = (p->nsfs - d) << 10;
         return;
     }
+    if (p->alloc1) {        // the first-generation allocator's measure (reference bitallo1.cpp:385-431): bands where one channel dominates count against M/S
+        int d = 0;
+        if (lane < p->nsf[0]) {
+            int k = p->startBand_l[lane], n = p->nBand_l[lane];
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int j = 0; j < n; j++, k++) {
+                float a = x0[k] * x0[k], b = x1[k] * x1[k];
+                s0 += (a + b);
+                a = fabsf(a - b);
+                s1 += a;
+            }
+            if ((double) s1 > 0.80 * (double) s0) d++;
+            if ((double) s1 > 0.95 * (double) s0) d += 2;
+        }
+        d = hx_wave_sum(d);
+        if (lane == 0) *out = p->nsf[0] - 3 * d;
+        return;
+    }
     if (lane < p->nsf[0]) {
         int k = p->startBand_l[lane], n = p->nBand_l[lane];
         float el = 100.0f, er = 100.0f, t = 0.0f;
@@ -599,15 +617,17 @@ __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const 
     HxStream *ss = st + s;
     const long long g0 = (long long) s * NG;
     if (lane == 0) {
-        const int on = prm[ss->cls].ms_flag;
+        const int on = prm[ss->cls].ms_flag, plain = prm[ss->cls].alloc1;    // (the first-generation allocator's measure takes no hysteresis)
         int mem = ss->ms_memory;
         for (int g = 0; g < NG; g += 2) {
             int m1 = 0, m2 = 0;
             if (on) {
                 m1 = msbase[g0 + g];
-                if (bt[g0 + g] == 2) mem = 0; else { m1 += mem; mem = (m1 > 0) ? 5000 : -5000; }
+                if (plain) { }
+                else if (bt[g0 + g] == 2) mem = 0; else { m1 += mem; mem = (m1 > 0) ? 5000 : -5000; }
                 m2 = msbase[g0 + g + 1];
-                if (bt[g0 + g + 1] == 2) mem = 0; else { m2 += mem; mem = (m2 > 0) ? 5000 : -5000; }
+                if (plain) { }
+                else if (bt[g0 + g + 1] == 2) mem = 0; else { m2 += mem; mem = (m2 > 0) ? 5000 : -5000; }
             }
             msdec[g0 + g] = m1;
             msdec[g0 + g + 1] = m2;
@@ -666,6 +686,7 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(float *__restrict__ xr, 
     // (from here on the wave works alone: LDS hand-overs inside a wave need no workgroup barrier)
 #define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
+    if (p->alloc1) return;      // the first-generation allocator starts from the raw spectrum
     const int ms = msflag[unit];
     const int two = p->nchan == 2;
     const int nsf0 = p->nsf[0];

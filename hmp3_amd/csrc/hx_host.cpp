@@ -328,6 +328,51 @@ static void psy_short_tables(HxParams *p)
 // Returns 0 when the configuration is outside what the MI355X path implements (the reference
 // would run dual-channel or intensity stereo there) or when the reference itself
 // rejects it (mp3enc.cpp:346-351,388); 9216 (bytes of float PCM per frame) otherwise.
+// Tables of the first-generation allocator (reference bitallo1.cpp:107-211 BitAlloInit, :444-543): expected
+// quantisation noise as a function of the quantised value (closed form of the x^(4/3) quantiser's cell), a bit
+// estimate per line by the band's largest value, the intensity position by the channels' energy ratio.
+static void alloc1_tables(HxParams *p)
+{
+    for (int i = 0; i < 21; i++) p->a1_log_cbw[i] = (float) (10.0 * log10((double) p->nBand_l_iso[i]));
+    for (int big = 0; big < 2; big++) {
+        double cum = 0.0;
+        for (int i = 0; i < 256; i++) {
+            const int ix = big ? 32 * i + 16 : i;
+            double t = ix + 0.5;
+            const double xh = t * pow(t, 1.0 / 3.0);
+            t = ix;
+            const double x0 = t * pow(t, 1.0 / 3.0);
+            t = ix - 0.5;
+            const double xl = t * pow(fabs(t), 1.0 / 3.0);
+            const double dh = xh - x0, dl = xl - x0;
+            const double eps = (dh * dh * dh - dl * dl * dl) / (3.0 * (xh - xl));
+            cum += eps;
+            (big ? p->a1_f_big_ix : p->a1_f_ix)[i] = (float) eps;
+            (big ? p->a1_f_big_ixmax : p->a1_f_ixmax)[i] = (float) (10.0 * log10(cum / (i + 1)));
+        }
+    }
+    p->a1_bits[0] = 0;
+    for (int m = 1; m < 256; m++) p->a1_bits[m] = (int) (16 * (1.4427 * log((double) (m + 1)) + (m - 0.6) / m));
+    p->a1_gz1 = (float) (16.0 / (3.0 * log(2.0)));
+    p->a1_gz2 = (float) (1 - (16.0 / (3.0 * log(2.0))) * log(.5946) + 8);
+    p->a1_gz0 = (float) (exp((0.99 - p->a1_gz2) / p->a1_gz1));
+    if (p->h_id) {
+        const double pi = 4.0 * atan(1.0);
+        for (int i = 0; i < 34; i++) p->a1_is_pos[i] = (int) (((12.0 / pi) * atan(sqrt(i / 32.0))) + .25);
+    } else
+        for (int i = 0; i < 34; i++) {
+            const int k = (int) (-log((i + .0001) / 32.0) / log(2.0) + 0.5);
+            p->a1_is_pos[i] = 2 * MN(MX(k, 0), 3);
+        }
+    p->a1_ill_is_pos = p->h_id ? 7 : 999;
+    p->a1_c707 = (float) (1.0 / sqrt(2.0));
+    static const float sp1[21] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.10f, 0.10f, 0.10f, 0.10f, 0.10f, 0.10f,
+                                  0.20f, 0.30f, 0.40f, 0.50f, 0.60f, 0.70f, 0.80f, 0.90f, 1.0f, 1.5f};
+    static const float sp2[21] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.10f, 0.10f, 0.10f, 0.10f, 0.10f, 0.10f,
+                                  0.20f, 0.30f, 0.40f, 0.50f, 0.50f, 0.60f, 0.70f, 0.80f, 0.90f};
+    memcpy(p->a1_sparse, p->h_id ? sp1 : sp2, sizeof(p->a1_sparse));
+}
+
 int hx_resolve(const HxControl *ec_arg, HxParams *p)
 {
     static const int sr_all[8] = {22050, 24000, 16000, 1, 44100, 48000, 32000, 1};
@@ -364,7 +409,6 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     p->sr_index = k & 3;
     p->tix = p->sr_index + 3 * (1 - h_id);
     const int *br_tab = h_id ? br_mpeg1_l3 : br_mpeg2_l3;
-    if (ec.mode == 2) return 0;                     // dual channel (legacy allocator): not on this path
     p->h_mode = ec.mode;
     p->nchan = (ec.mode == 3) ? 1 : 2;
     int mode_ext = (p->h_mode == 1) ? ec.nsbstereo / 4 - 1 : 0;
@@ -458,7 +502,11 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     int is_flag = 0;
     p->ms_flag = 0;
     if (p->h_mode == 1) { if (nsbstereo_limit < p->nsb_limit) is_flag = 1; p->ms_flag = 1; }
-    if (is_flag) return 0;                          // intensity stereo (legacy allocator): not on this path
+    // the reference's first-generation allocator codes these (mp3enc.cpp:696-766): long blocks only
+    p->is_flag = is_flag;
+    p->alloc1 = is_flag || p->h_mode == 2;
+    if (is_flag) ec.vbr_flag = 0;
+    if (p->alloc1) p->short_block_threshold = 0x7fffffff;       // its drivers never look at the transient detector
     p->vbr_flag = ec.vbr_flag;
     if (ec.vbr_flag) {                              // gen_vbr_table (mp3enc.cpp:964-1041)
         for (int i = 1; i < 15; i++) {
@@ -532,11 +580,12 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     p->initialMNR += 10 * ec.vbr_delta_mnr - (h_id ? 0 : 300);         // bitallo3.cpp:446-453
     for (int i = 0; i < 22; i++) if (p->nBand_l[i] != 0) p->rnBand_l[i] = (1.0f / p->nBand_l[i]);
 
+    if (p->alloc1) alloc1_tables(p);
     p->ec = ec;
     p->ec.mode = p->h_mode;
     p->ec.bitrate = p->totbitrate / p->nchan;
     p->ec.samprate = p->samprate;
-    p->ec.nsbstereo = 32;
+    p->ec.nsbstereo = is_flag ? nsbstereo : 32;
     p->ec.freq_limit = ec.hf_flag ? ec.freq_limit : p->nsb_limit * (p->samprate / 64);
     p->ec.nsb_limit = p->nsb_limit;
     p->ec.layer = 3;
@@ -553,4 +602,10 @@ void hx_stream_reset(const HxParams *p, int cls, HxStream *s)
     s->MNR = p->initialMNR;
     s->PoolFraction = p->vbr_flag ? 614 : 0;
     s->padcount = p->divisor;
+    if (p->alloc1) {        // bitallo1.cpp:163-196
+        for (int c = 0; c < 2; c++) for (int j = 0; j < p->nsf[c]; j++) s->a1_gsf[c][j] = 35;
+        s->a1_bitadjust[0] = s->a1_bitadjust[1] = -100;
+        s->a1_running_a = (1.0f / 20.0f);
+        s->a1_ave_alpha = 40.0f;
+    }
 }

@@ -62,6 +62,13 @@ struct HxParams {
     // short-block allocator (reference bitallos.cpp:128-200)
     int nsfs, nbmax_s, look_log_cbwmb_s[16];
     unsigned char sband_of_line[192];   // short sfb index of each line of a 192-line window
+    // streams the reference codes with its first-generation allocator (CBitAllo1, bitallo1.cpp): joint stereo with an
+    // intensity part (is_flag) and dual channel.  Long blocks only; tables of bitallo1.cpp:107-211,444-543
+    int is_flag, alloc1, a1_ill_is_pos;
+    float a1_log_cbw[21];                       // 10 log10(band width)
+    float a1_f_ix[256], a1_f_ixmax[256], a1_f_big_ix[256], a1_f_big_ixmax[256];    // noise estimators by quantised value
+    int a1_bits[256], a1_is_pos[34];            // bit estimator x 16; intensity position by energy ratio
+    float a1_gz0, a1_gz1, a1_gz2, a1_c707, a1_sparse[21];
 };
 
 // Class-independent tables.
@@ -105,6 +112,10 @@ struct HxStream {
     float thr_prev[2][64];      // previous granule's unclamped thresholds x 2 (ecsave)
     // allocator
     int MNR, PoolFraction, call_count, ms_memory, NTadjust[2][22];
+    // first-generation allocator (pub/bitallo1.h:80-140): gain steps carried per channel, bit-estimate feedback,
+    // running noise-to-mask level
+    int a1_gsf[2][21], a1_bitadjust[2], a1_call_count;
+    float a1_running_a, a1_ave_alpha, a1_alpha;
     int sf_save[2][21];
     int gr_subblock_gain[2][2][3];
     // reservoir / frame assembly (mp3enc.cpp:2230-2333)

@@ -48,6 +48,12 @@ CASES = {
     "cli_src_48k_to_24k_s24": (923, 40001, 48000, 24, True, ["-A2", "-B32"]),             # 2:1 down, one filter bank
     "cli_src_44k_to_32k_s16": (924, 40003, 44100, False, True, ["-A32000", "-B64"]),      # 441:320 down, two stages
     "cli_src_44k_to_22k_downmix": (925, 40007, 44100, False, False, ["-A22050", "-M3", "-V50"]),   # down + down-mix
+    # the reference's first-generation allocator: intensity stereo (MPEG-2 below 48 kbps total; MPEG-1 on request, -N), dual channel (-M2)
+    "cli_is_lsf_cbr32_s16_22k": (926, 50003, 22050, False, True, ["-B16"]),
+    "cli_is_lsf_cbr16_f32_16k": (927, 40001, 16000, True, False, ["-B8"]),
+    "cli_is_n8_cbr128_s16_44k": (928, 60007, 44100, False, True, ["-B64", "-N8"]),
+    "cli_dual_cbr128_s24_44k": (929, 50021, 44100, 24, True, ["-B64", "-M2"]),
+    "cli_dual_lsf_cbr48_s16_24k": (930, 40009, 24000, False, False, ["-B24", "-M2"]),
 }
 CONTAINER = {"cli_rifx_cbr64_s16_44k": "rifx", "cli_rf64_vbr50_s16_48k": "rf64", "cli_w64_cbr64_s24_44k": "w64",
              "cli_ext_vbr60_s24_48k": "ext"}

@@ -84,7 +84,9 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
                                   "cli_rifx_cbr64_s16_44k", "cli_rf64_vbr50_s16_48k", "cli_w64_cbr64_s24_44k",
                                   "cli_ext_vbr60_s24_48k", "cli_odd_cbr64_u8_mono_44k",
                                   "cli_src_11k_to_22k_s16", "cli_src_8k_to_16k_u8_mono", "cli_src_32k_to_44k_f32",
-                                  "cli_src_48k_to_24k_s24", "cli_src_44k_to_32k_s16", "cli_src_44k_to_22k_downmix"])
+                                  "cli_src_48k_to_24k_s24", "cli_src_44k_to_32k_s16", "cli_src_44k_to_22k_downmix",
+                                  "cli_is_lsf_cbr32_s16_22k", "cli_is_lsf_cbr16_f32_16k", "cli_is_n8_cbr128_s16_44k",
+                                  "cli_dual_cbr128_s24_44k", "cli_dual_lsf_cbr48_s16_24k"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     """hmp3_amd/hmp3amd (GPU path + Xing/Info tag + WAV front end) against files written by the real
     reference CLI (tests/golden/cli_*.mp3, tests/golden/make_golden_cli.py)"""
@@ -230,6 +232,65 @@ def test_mpeg2_batch_byte_identical_to_oracle(name):
     assert all(f[1] == len(got[i]) + len(got2[i]) for i, f in enumerate(fb))
     assert all(2 * F - 34 <= f[0] <= 2 * F for f in fb)        # two frames per block, less what is still pending
     b.close()
+
+
+A1 = {
+    # streams the reference codes with its first-generation allocator (CBitAllo1): joint stereo with an intensity part
+    # (at MPEG-1 rates only on request, E_CONTROL nsbstereo / -N; at MPEG-2 rates below 48 kbps total) and dual channel
+    "is_n8_cbr128_44k": (dict(bitrate=64, nsbstereo=8), 44100),
+    "is_n4_cbr96_48k": (dict(bitrate=48, nsbstereo=4, samprate=48000), 48000),
+    "is_n12_cbr112_32k": (dict(bitrate=56, nsbstereo=12, samprate=32000), 32000),
+    "is_n16_cbr192_44k_dc": (dict(bitrate=96, nsbstereo=16, filter_select=1), 44100),
+    "dual_cbr128": (dict(bitrate=64, mode=2), 44100),
+    "dual_cbr96_48k": (dict(bitrate=48, mode=2, samprate=48000), 48000),
+    "dual_cbr320": (dict(bitrate=160, mode=2), 44100),
+    "lsf_is_cbr32_22k": (dict(bitrate=16, samprate=22050), 22050),
+    "lsf_is_cbr16_16k": (dict(bitrate=8, samprate=16000), 16000),
+    "lsf_is_cbr40_24k": (dict(bitrate=20, samprate=24000), 24000),
+    "lsf_dual_cbr64_22k": (dict(bitrate=32, samprate=22050, mode=2), 22050),
+    "lsf_dual_cbr32_16k": (dict(bitrate=16, samprate=16000, mode=2), 16000),
+}
+
+
+@pytest.mark.parametrize("name", list(A1))
+def test_intensity_stereo_and_dual_channel_byte_identical_to_oracle(name):
+    """the kernels k_alloc1 / k_alloc1_lsf (hx_alloc1.inc): 8 streams of differing channel correlation, ragged calls"""
+    kw, sr = A1[name]
+    S, F = 8, 40
+    pcm = np.stack([synth.stream_pcm(5200 + i, F, sr=sr, rho=RHOS[i % 4], bursts=(i % 2 == 0)) for i in range(S)])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=24)
+    got = [b"" for _ in range(S)]
+    pos = 0
+    for n in (3, 24, 13):
+        out = b.encode_host(pcm[:, pos * 1152:(pos + n) * 1152])
+        pos += n
+        for s in range(S):
+            got[s] += out[s]
+    assert b.status() == 0
+    for s in range(S):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), (name, s)
+    b.close()
+
+
+def test_intensity_stereo_stress_signals():
+    """full-scale noise, a pure tone on both channels, silence, near-silence, anti-phase tone: the allocator's bit
+    seek in both directions, silent channels, intensity positions at the extremes"""
+    F = 24
+    n = F * 1152
+    rng = np.random.default_rng(99)
+    t = np.arange(n)
+    noise = rng.integers(-32768, 32768, (n, 2)).astype(np.int16)
+    tone = np.round(32767 * np.sin(2 * np.pi * 110.0 * t / 44100.0)).astype(np.int16)
+    sigs = [noise, np.stack([tone, tone], axis=1), np.zeros((n, 2), np.int16), (noise // 4096).astype(np.int16),
+            np.stack([tone, -tone], axis=1), np.stack([tone, np.zeros(n, np.int16)], axis=1)]
+    pcm = np.stack(sigs)
+    for kw in (dict(bitrate=64, nsbstereo=6), dict(bitrate=64, mode=2), dict(bitrate=16, samprate=22050), dict(bitrate=32, samprate=16000, mode=2)):
+        b = api().Batch(api().default_control(**kw), nstreams=len(sigs), max_frames=F)
+        got = b.encode_host(pcm)
+        assert b.status() == 0
+        for s in range(len(sigs)):
+            assert got[s] == oracle_bytes(kw, pcm[s], F), (kw, s)
+        b.close()
 
 
 def test_mpeg2_and_mpeg1_cannot_share_a_batch():
@@ -718,8 +779,10 @@ def test_api_misuse_fails_loudly_and_leaves_the_batch_usable():
     a = api()
     with pytest.raises(RuntimeError):           # mono and stereo streams cannot share a batch
         a.Batch([a.default_control(bitrate=64), a.default_control(bitrate=64, mode=3)], nstreams=2, max_frames=4)
-    with pytest.raises(RuntimeError):           # dual channel is not built
-        a.Batch(a.default_control(bitrate=64, mode=2), nstreams=1, max_frames=4)
+    with pytest.raises(RuntimeError):           # streams of the two allocator generations cannot share a batch
+        a.Batch([a.default_control(bitrate=64), a.default_control(bitrate=64, mode=2)], nstreams=2, max_frames=4)
+    with pytest.raises(RuntimeError):           # CBR below 48 kbps per channel at an MPEG-1 rate: rejected like the reference does
+        a.Batch(a.default_control(bitrate=32), nstreams=1, max_frames=4)
     b = a.Batch(a.default_control(bitrate=64), nstreams=2, max_frames=4)
     pcm = np.stack([synth.stream_pcm(5, 8), synth.stream_pcm(6, 8)])
     with pytest.raises(RuntimeError):           # more frames than the batch was created for

@@ -94,9 +94,11 @@ def test_resolve_rejects_what_reference_rejects_and_out_of_scope():
     assert not ok(bitrate=40)               # mp3enc.cpp:346-351
     assert not ok(bitrate=64, layer=2)      # mp3enc.cpp:388
     assert ok(bitrate=64, mode=3)           # mono
-    assert not ok(bitrate=64, mode=2)       # dual channel: documented out of scope
+    assert ok(bitrate=64, mode=2)           # dual channel (first-generation allocator)
+    assert not ok(bitrate=40, mode=2)       # ... under the same CBR floor
     assert ok(bitrate=32, samprate=22050)       # MPEG-2 LSF
-    assert not ok(bitrate=8, samprate=16000)    # 16 kbps joint stereo turns intensity stereo on: documented out of scope
+    assert ok(bitrate=8, samprate=16000)        # 16 kbps joint stereo: intensity stereo (first-generation allocator)
+    assert ok(bitrate=64, nsbstereo=8)          # intensity stereo on request at an MPEG-1 rate
     assert not ok(bitrate=64, samprate=5000)    # nearest entry of the rate table is a reserved index
 
 

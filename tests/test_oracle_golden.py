@@ -102,11 +102,11 @@ def test_init_rejections_follow_reference():
     # mp3enc.cpp:346-351: CBR below 48 kbps per channel above 24 kHz; Layer != III (mp3enc.cpp:388)
     assert not O.OracleEncoder(O.default_control(bitrate=40)).ok()
     assert not O.OracleEncoder(O.default_control(bitrate=64, layer=2)).ok()
-    # outside this path's scope (documented): dual channel and intensity stereo (CBitAllo1)
-    assert O.OracleEncoder(O.default_control(bitrate=64, mode=3)).ok()      # mono is restated
-    assert not O.OracleEncoder(O.default_control(bitrate=64, mode=2)).ok()  # dual channel: out of scope
-    assert O.OracleEncoder(O.default_control(bitrate=32, samprate=22050)).ok()      # MPEG-2 LSF is restated
-    assert not O.OracleEncoder(O.default_control(bitrate=8, samprate=16000)).ok()   # 16 kbps joint stereo -> intensity
+    assert O.OracleEncoder(O.default_control(bitrate=64, mode=3)).ok()      # mono
+    assert O.OracleEncoder(O.default_control(bitrate=64, mode=2)).ok()      # dual channel (first-generation allocator)
+    assert not O.OracleEncoder(O.default_control(bitrate=40, mode=2)).ok()
+    assert O.OracleEncoder(O.default_control(bitrate=32, samprate=22050)).ok()      # MPEG-2 LSF
+    assert O.OracleEncoder(O.default_control(bitrate=8, samprate=16000)).ok()       # 16 kbps joint stereo: intensity stereo
     assert O.OracleEncoder(O.default_control(bitrate=64)).bytes_in == 9216
 
 
