@@ -44,6 +44,21 @@ struct AllocPrm {
     int oflags;                         // optional outputs of the call: 1 = packets, 2 = debug taps, 4 = per-frame counters
 };
 
+// What the master wave hands to global memory in the frame loop - the k_pack records of a granule's channels and,
+// when the granule ends a frame, the frame's header, side information, record and slot - collects here and is
+// stored by the helper wave a granule later.  A store of the master's own would stand in its in-order memory queue
+// ahead of every later load (scratch reloads included), which then waits a memory round trip for the write's
+// acknowledgement.  Two boxes: granule g fills box g & 1 while the helper empties the other.
+struct alignas(16) Outbox {
+    HxSegOut seg[2];
+    unsigned sidew[10];                 // side information, MSB-first words
+    unsigned char head[4];
+    HxFrameOut frm;
+    HxSlot slot;
+    int opos, frm_index, slot_index;    // where they go: header offset in the stream's output, frame and slot number
+    int has_frame;
+};
+
 struct alignas(16) AllocLds {
     float xr[2][576];
     float x34[2][576];
@@ -111,6 +126,7 @@ struct alignas(16) AllocLds {
     unsigned short r_mf[32];            // pending frames: main-data bytes of the slot ...
     int r_off[32];                      // ... and offset of its header in the output buffer
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
+    Outbox ob[2];
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
 #ifdef HX_PROFILE
     unsigned prof[36];                  // 36 slots x 4 bytes keeps the profile build at four workgroups per CU
