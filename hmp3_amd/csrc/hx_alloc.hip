@@ -49,9 +49,12 @@ struct AllocPrm {
 // stored by the helper wave a granule later.  A store of the master's own would stand in its in-order memory queue
 // ahead of every later load (scratch reloads included), which then waits a memory round trip for the write's
 // acknowledgement.  Two boxes: granule g fills box g & 1 while the helper empties the other.
+static_assert(sizeof(HxGr) == 96, "the frame loop copies the four HxGr of a frame as 96 words");
 struct alignas(16) Outbox {
     HxSegOut seg[2];
-    unsigned sidew[10];                 // side information, MSB-first words
+    HxGr gr[2][2];                      // the frame's side information as the allocator left it, its scfsi bits and
+    int scfsi[2], mdb, part;            // main_data_begin (MPEG-2: which granule): the helper wave builds the bits
+    unsigned sidew[10];                 // side information, MSB-first words (the helper's staging)
     unsigned char head[4];
     HxFrameOut frm;
     HxSlot slot;
@@ -65,8 +68,7 @@ struct alignas(16) AllocLds {
     float term[2][576];
     int ix[2][576];
     unsigned char signx[2][576];
-    alignas(16) unsigned char sgn_next[2][576];     // the next granule's signs and band start values, landed by LDS-DMA while
-    HxBandPrep band_next;                           // this granule's copies are still in use
+    alignas(16) HxBandPrep band_next;               // the next granule's band start values, landed by LDS-DMA while this granule's are still in use
     unsigned char band_of_line[576];
     // tables staged from global memory
     float look_ix43[256], look_gain[128], look_34igain[128];
