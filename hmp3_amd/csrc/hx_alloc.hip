@@ -747,32 +747,31 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 // quantise channel c's lines with the band gains published in L.gig, track the band maxima
 __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int opt, int c)
 {
+    // all nine lines of a lane in one basic block: band -> igain -> rounding offset are dependent LDS reads, the nine
+    // chains overlap; stores (and the band maxima) come after all loads
     const int nl = p->nbmax[c];
-#pragma unroll 1
-    for (int c3 = 0; c3 < 3; c3++) {
-        if (192 * c3 >= nl) continue;
-        int q[3], b[3];
+    int q[9], b[9];
 #pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int j = LANE + 64 * (3 * c3 + k3);
-            b[k3] = L.band_of_line[j];
-            const float igain = L.gig[c][b[k3]];
-            if (opt) {
-                float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
-                int iq = (int) t;
-                if (iq > 31) iq = 31;
-                q[k3] = (int) (t - L.quant_off[iq < 0 ? 0 : iq]);
-            } else {
-                q[k3] = (int) (igain * L.x34[c][j] + (0.5f - 0.0946f));
-            }
+    for (int k = 0; k < 9; k++) b[k] = L.band_of_line[LANE + 64 * k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int j = LANE + 64 * k;
+        const float igain = L.gig[c][b[k]];
+        if (opt) {
+            float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
+            int iq = (int) t;
+            if (iq > 31) iq = 31;
+            q[k] = (int) (t - L.quant_off[iq < 0 ? 0 : iq]);
+        } else {
+            q[k] = (int) (igain * L.x34[c][j] + (0.5f - 0.0946f));
         }
+    }
 #pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int j = LANE + 64 * (3 * c3 + k3);
-            if (j < nl) {
-                L.ix[c][j] = q[k3];
-                if (q[k3] > 0) atomicMax(&L.ixmax[c][b[k3]], q[k3]);
-            }
+    for (int k = 0; k < 9; k++) {
+        const int j = LANE + 64 * k;
+        if (j < nl) {
+            L.ix[c][j] = q[k];
+            if (q[k] > 0) atomicMax(&L.ixmax[c][b[k]], q[k]);
         }
     }
 }
