@@ -129,6 +129,7 @@ struct alignas(16) AllocLds {
     int r_off[32];                      // ... and offset of its header in the output buffer
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
     Outbox ob[2];
+    const double *pow43;                // HxGlobalTabs::pow43 (global memory)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
 #ifdef HX_PROFILE
     unsigned prof[36];                  // 36 slots x 4 bytes keeps the profile build at four workgroups per CU
@@ -232,13 +233,14 @@ __device__ __forceinline__ float noise_term(const AllocLds &L, float igain, floa
     tmp = x - xhat;
     return tmp * tmp;
 }
-__device__ __noinline__ float noise_term_slow(float igain, float gain, float x34, float x)
+// The reference's value beyond the float table: gain * pow(ix, 4/3) in double.  ix^(4/3) comes from the double table
+// in global memory (host pow(), as the reference calls it); pow() itself only past the table's 16384 entries.
+__device__ __noinline__ double pow43_beyond(int qx) { return pow((double) qx, (4.0 / 3.0)); }
+__device__ __forceinline__ float noise_xhat_big(const AllocLds &L, int qx, double pw_tab, float gain)
 {
-    float tmp = (igain * x34 + (0.0f - 0.0946f));
-    const int qx = (int) (tmp + copysignf(0.5f, tmp));
-    const float xhat = (float) (gain * pow((double) qx, (4.0 / 3.0)));
-    tmp = x - xhat;
-    return tmp * tmp;
+    double pw = pw_tab;
+    if (qx >= HX_POW43_N) pw = pow43_beyond(qx);
+    return (float) (gain * pw);
 }
 
 // Table-only variant for the hot loops: the index is clamped into the table, and the caller has
@@ -296,6 +298,38 @@ __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int
     }
 }
 
+// The same sweep when some evaluated band may quantise beyond the float table (decided per sweep from the band
+// maxima; loud near-mono material at low gain steps): terms beyond the table come from the double table.  Out of
+// line and from LDS instead of the caller's registers, three lines at a time, so that the rare case costs the common
+// path neither registers nor code.  (Bands that are not evaluated quantise to <= 0.)
+__device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl)
+{
+#pragma unroll 1
+    for (int c3 = 0; c3 < 3; c3++) {
+        if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
+        float t[3], gn[3], xr[3];
+        int qx[3];
+        double pw[3];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            const int j = LANE + 64 * (3 * c3 + k3), bnd = L.band_of_line[j];
+            const float ig = L.gig[ch][bnd], x34 = L.x34[ch][j];
+            gn[k3] = L.gg[ch][bnd];
+            xr[k3] = L.xr[ch][j];
+            const float tmp = (ig * x34 + (0.0f - 0.0946f));
+            qx[k3] = (int) (tmp + copysignf(0.5f, tmp));
+            t[k3] = noise_term_fast(L, ig, gn[k3], x34, xr[k3]);
+        }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) pw[k3] = L.pow43[min(max(qx[k3], 0), HX_POW43_N - 1)];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++)
+            if (qx[k3] >= 256) { const float d = xr[k3] - noise_xhat_big(L, qx[k3], pw[k3], gn[k3]); t[k3] = d * d; }
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
+    }
+}
+
 // One sweep of the gain search for channel ch, run by one wave on its own (the master wave does
 // channel 0 while the helper wave does channel 1: gain pairs, terms and sums of the two channels live
 // in separate LDS arrays, so the waves never wait for each other inside a search).  Band lane i < 32
@@ -319,18 +353,8 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     SYNC();
     PROF_ACC(27);
     const int nl = min(nlines, hi);
-    sweep_lines(L, R, ch, lo, nl);
-    if (__any(bslow)) {     // some band reaches beyond the table: rare, redo its lines with pow()
-        for (int j = lo + LANE; j < nl; j += 64) {
-            const int bnd = L.band_of_line[j];
-            const float igain = L.gig[ch][bnd];
-            bool fast;
-            if (igain >= 0.0f) {
-                noise_term(L, igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j], &fast);
-                if (!fast) L.term[ch][j] = noise_term_slow(igain, L.gg[ch][bnd], L.x34[ch][j], L.xr[ch][j]);
-            }
-        }
-    }
+    if (__builtin_expect(__any(bslow), 0)) sweep_lines_big(L, ch, lo, nl);
+    else sweep_lines(L, R, ch, lo, nl);
     SYNC();
     PROF_ACC(28);
     int noise = 0;
@@ -644,6 +668,34 @@ __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, floa
     }
 }
 
+// big_lucky's terms beyond the 256-entry table, redone (see sweep_fix_big)
+__device__ __noinline__ void lucky_fix_big(AllocLds &L, int nl, int ncmax, float *tf)
+{
+    for (int c = 0; c < ncmax; c++)
+        for (int t0 = 0; t0 < 2 * nl; t0 += 256) {
+            int qx[4];
+            float gn[4], xr[4];
+            double pw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = t0 + LANE + 64 * k, tt = min(t, 2 * nl - 1);
+                const int cc = tt >= nl, j = tt - (cc ? nl : 0), b = L.band_of_line[j];
+                const int ge = L.geval[cc][b];
+                const int g = min(max(ge, 0) + c * 2 * (1 + L.scale[cc]), 127);
+                gn[k] = L.look_gain[g];
+                xr[k] = L.xr[cc][j];
+                const float tmp = (L.look_34igain[g] * L.x34[cc][j] + (0.0f - 0.0946f));
+                const int q = (int) (tmp + copysignf(0.5f, tmp));
+                qx[k] = (t < 2 * nl && ge >= 0 && c < L.tmpn[cc][b] && q >= 256) ? q : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) pw[k] = L.pow43[min(qx[k], HX_POW43_N - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (qx[k]) { const float d = xr[k] - noise_xhat_big(L, qx[k], pw[k], gn[k]); tf[c * 2 * nl + t0 + LANE + 64 * k] = d * d; }
+        }
+}
+
 // reference bitallo3.cpp:1348-1396
 __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 {
@@ -697,18 +749,7 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
             if (!HX_LSF || 2 * nl <= 256) lucky_terms<2>(L, nl, ncmax, tf, 1);
             else lucky_terms<3>(L, nl, ncmax, tf, 1);
         }
-        if (__any(bslow)) {     // a band reaches beyond the 256-entry table: rare, redo with pow()
-            for (int c = 0; c < ncmax; c++)
-                for (int t = LANE; t < 2 * nl; t += 64) {
-                    const int cc = t >= nl, j = t - (cc ? nl : 0), b = L.band_of_line[j];
-                    if (L.geval[cc][b] >= 0 && c < L.tmpn[cc][b]) {
-                        const int g = min(L.geval[cc][b] + c * 2 * (1 + L.scale[cc]), 127);
-                        bool fast;
-                        noise_term(L, L.look_34igain[g], L.look_gain[g], L.x34[cc][j], L.xr[cc][j], &fast);
-                        if (!fast) tf[c * 2 * nl + t] = noise_term_slow(L.look_34igain[g], L.look_gain[g], L.x34[cc][j], L.xr[cc][j]);
-                    }
-                }
-        }
+        if (__any(bslow)) lucky_fix_big(L, nl, ncmax, tf);     // a band reaches beyond the 256-entry table
         SYNC();
         PROF_ACC(24);
         for (int u = LANE; u < total; u += 64) {

@@ -198,7 +198,8 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     }
     b->ncls = (int) b->params.size();
     const long long S = nstreams, NG = 2LL * max_frames;
-    HxGlobalTabs gt;
+    std::vector<HxGlobalTabs> gt_host(1);       // (144 KB: not on the stack)
+    HxGlobalTabs &gt = gt_host[0];
     hx_global_tabs(&gt);
     std::vector<HxStream> st(nstreams);
     for (int s = 0; s < nstreams; s++) hx_stream_reset(&b->params[b->cls_of[s]], b->cls_of[s], &st[s]);

@@ -65,6 +65,7 @@ void hx_global_tabs(HxGlobalTabs *g)
         0.00362, 0.00333, 0.00309, 0.00287, 0.00269, 0.00253, 0.00238, 0.00225, 0.00214, 0.00203, 0.00194,
         0.00185, 0.00177, 0.00170, 0.00163, 0.00157, 0.00152, 0.00146, 0.00141, 0.00136, 0.00132};
     memset(g, 0, sizeof(*g));
+    for (int i = 0; i < HX_POW43_N; i++) g->pow43[i] = pow((double) i, (4.0 / 3.0));
     for (int i = 0; i < 512; i++) g->anwin[i] = bits2f(HX_ANWIN_BITS[i]);
     // K1 folds the 512 taps to 32 sums; output k adds taps A + 64 j and B + 64 j (j = 0..7)
     for (int k = 0; k < 32; k++) {

@@ -72,7 +72,9 @@ struct HxParams {
 };
 
 // Class-independent tables.
+#define HX_POW43_N 16384             // quantised values covered by the double-precision x^(4/3) table
 struct HxGlobalTabs {
+    double pow43[HX_POW43_N];           // i^(4/3) as the reference's pow() call returns it (noise of lines quantised beyond the 256-entry float table)
     float anwin[512];
     float anwin_r[512];                 // the same window in the order K1 uses it: [k][j][A tap, B tap]
     int mblog[256];

@@ -5,8 +5,9 @@ import numpy as np
 from hmp3_amd import api, synth
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-kw = dict(bitrate=64, short_block_threshold=99999)
-pcm = synth.batch_pcm(S, F, unique=16)
+import json
+kw = json.loads(os.environ["PROF_KW"]) if "PROF_KW" in os.environ else dict(bitrate=64, short_block_threshold=99999)
+pcm = synth.batch_pcm(S, F, unique=16, bursts=bool(int(os.environ.get("PROF_BURSTS", "0"))), rho=float(os.environ.get("PROF_RHO", "0.7")))
 b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
 b.debug_enable(True)
 b.encode_host(pcm)
