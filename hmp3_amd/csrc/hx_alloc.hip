@@ -668,32 +668,59 @@ __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, floa
     }
 }
 
-// big_lucky's terms beyond the 256-entry table, redone (see sweep_fix_big)
-__device__ __noinline__ void lucky_fix_big(AllocLds &L, int nl, int ncmax, float *tf)
+// The same with terms beyond the 256-entry table taken from the double table (see sweep_lines_big): out of line, one
+// candidate at a time.
+template <int NQ>
+__device__ __noinline__ void lucky_terms_big(AllocLds &L, int nl, int ncmax, float *tf, int w)
 {
-    for (int c = 0; c < ncmax; c++)
-        for (int t0 = 0; t0 < 2 * nl; t0 += 256) {
-            int qx[4];
-            float gn[4], xr[4];
-            double pw[4];
+    float sx34[NQ], sxr[NQ];
+    int sg[NQ], ssd[NQ], stride[NQ];
+    float *base[NQ];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int t = t0 + LANE + 64 * k, tt = min(t, 2 * nl - 1);
-                const int cc = tt >= nl, j = tt - (cc ? nl : 0), b = L.band_of_line[j];
-                const int ge = L.geval[cc][b];
-                const int g = min(max(ge, 0) + c * 2 * (1 + L.scale[cc]), 127);
-                gn[k] = L.look_gain[g];
-                xr[k] = L.xr[cc][j];
-                const float tmp = (L.look_34igain[g] * L.x34[cc][j] + (0.0f - 0.0946f));
-                const int q = (int) (tmp + copysignf(0.5f, tmp));
-                qx[k] = (t < 2 * nl && ge >= 0 && c < L.tmpn[cc][b] && q >= 256) ? q : 0;
-            }
+    for (int q = 0; q < NQ; q++) {
+        const int t = LANE + 64 * (2 * q + w);
+        const bool ok = t < 2 * nl;
+        const int cc = (ok && t >= nl) ? 1 : 0, j = ok ? t - (cc ? nl : 0) : 0;
+        sx34[q] = L.x34[cc][j];
+        sxr[q] = L.xr[cc][j];
+        sg[q] = max(L.geval[cc][L.band_of_line[j]], 0);
+        ssd[q] = 2 * (1 + L.scale[cc]);
+        base[q] = ok ? &tf[t] : &L.dump[LANE];
+        stride[q] = ok ? 2 * nl : 0;
+    }
+#pragma unroll 1
+    for (int c = 0; c < ncmax; c++) {
+        float v[NQ], gn[NQ];
+        int qx[NQ];
+        double pw[NQ];
 #pragma unroll
-            for (int k = 0; k < 4; k++) pw[k] = L.pow43[min(qx[k], HX_POW43_N - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (qx[k]) { const float d = xr[k] - noise_xhat_big(L, qx[k], pw[k], gn[k]); tf[c * 2 * nl + t0 + LANE + 64 * k] = d * d; }
+        for (int q = 0; q < NQ; q++) {
+            const int g = min(sg[q] + c * ssd[q], 127);
+            const float ig = L.look_34igain[g];
+            gn[q] = L.look_gain[g];
+            const float tmp = (ig * sx34[q] + (0.0f - 0.0946f));
+            qx[q] = (int) (tmp + copysignf(0.5f, tmp));
+            v[q] = noise_term_fast(L, ig, gn[q], sx34[q], sxr[q]);
         }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) pw[q] = L.pow43[min(max(qx[q], 0), HX_POW43_N - 1)];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (qx[q] >= 256) { const float d = sxr[q] - noise_xhat_big(L, qx[q], pw[q], gn[q]); v[q] = d * d; }
+            base[q][c * stride[q]] = v[q];
+        }
+    }
+}
+
+__device__ __forceinline__ void lucky_dispatch(AllocLds &L, int nl, int ncmax, float *tf, int w, int big)
+{
+    if (__builtin_expect(big, 0)) {
+        if (!HX_LSF || 2 * nl <= 256) lucky_terms_big<2>(L, nl, ncmax, tf, w);
+        else lucky_terms_big<3>(L, nl, ncmax, tf, w);
+    } else {
+        if (!HX_LSF || 2 * nl <= 256) lucky_terms<2>(L, nl, ncmax, tf, w);
+        else lucky_terms<3>(L, nl, ncmax, tf, w);
+    }
 }
 
 // reference bitallo3.cpp:1348-1396
@@ -741,15 +768,11 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
         PROF_ACC(23);
         // slots of 64 flattened lines: 3 or 4 (MPEG-2 band tables: 5), shared between the two waves
         const bool two = p->nchan == 2;
-        if (two) HELPER_POST2(HCMD_LUCKY, nl, ncmax);
-        if (!HX_LSF || 2 * nl <= 256) lucky_terms<2>(L, nl, ncmax, tf, 0);
-        else lucky_terms<3>(L, nl, ncmax, tf, 0);
+        const int big = __any(bslow) ? 1 : 0;       // a band reaches beyond the 256-entry table
+        if (two) { if (LANE == 0) L.cmdw[3] = big; HELPER_POST2(HCMD_LUCKY, nl, ncmax); }
+        lucky_dispatch(L, nl, ncmax, tf, 0, big);
         if (two) HELPER_JOIN();
-        else {
-            if (!HX_LSF || 2 * nl <= 256) lucky_terms<2>(L, nl, ncmax, tf, 1);
-            else lucky_terms<3>(L, nl, ncmax, tf, 1);
-        }
-        if (__any(bslow)) lucky_fix_big(L, nl, ncmax, tf);     // a band reaches beyond the 256-entry table
+        else lucky_dispatch(L, nl, ncmax, tf, 1, big);
         SYNC();
         PROF_ACC(24);
         for (int u = LANE; u < total; u += 64) {
