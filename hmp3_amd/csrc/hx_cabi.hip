@@ -15,7 +15,7 @@
 // kernels (hx_front.hip / hx_alloc.hip)
 #define K1_GPB 14
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
-                            const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan);
+                            const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan, int *eng, int lsf);
 __global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S, int nchan);
 __global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total, int lsf);
 __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
@@ -438,9 +438,10 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
     const float *pcmf = b->any_dc ? b->d_pcmf : d_pcm32;       // fp32 samples the polyphase reads, or null for int16
     if (b->any_dc) LAUNCH(k_dcfilter, dim3((b->nchan * S + 63) / 64), dim3(64), q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S, b->nchan);
-    LAUNCH(k_polyphase, g1, dim3(512), q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan);
-    int tot = (int) ((long long) S * 2 * NG * 9);       // < 2^31: hx_batch_create bounds nstreams * max_frames
+    // (the carry in slots 0..2 is not written by k_polyphase, so the two may run in either order)
+    int tot = S * 2 * 9;
     LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot, b->lsf);
+    LAUNCH(k_polyphase, g1, dim3(512), q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan, b->d_eng, b->lsf);
     tot = S * NG;
     LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
            b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
                                                    const HxParams *__restrict__ prm,
                                                    const HxGlobalTabs *__restrict__ gt,
                                                    float *__restrict__ sb, int NG, int SG,
-                                                   const float *__restrict__ pcmf, int nchan)
+                                                   const float *__restrict__ pcmf, int nchan, int *__restrict__ eng, int lsf)
 {
     __shared__ float xs2[2][K1_LDS];
     __shared__ __attribute__((aligned(16))) float wr[512];
@@ -113,10 +113,17 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
         xs2[c][i + (i >> 5)] = ss->pcm_hist[c][i];
     }
     __syncthreads();
-    if (ch >= nchan) return;
-    const float *xs = xs2[ch];
     const int gl = lt / 18, t = lt - gl * 18;
     if (gl >= ng) return;
+    // transient detector input (reference detect.c:147-196): energy of subbands 4..17 (MPEG-2 LSF rates: 8..27) per pair
+    // of time slots, as mB; eng index g <-> the granule one before coded granule g, so this granule's go to index + 1
+    // (the last granule's are next call's index 0, which k_attack_eng forms from the carry).
+    int *eo = (!(t & 1) && g0 + gl + 1 < NG) ? eng + ((long long) (s * 2 + ch) * NG + g0 + gl + 1) * 9 + (t >> 1) : nullptr;
+    if (ch >= nchan) {      // mono batch: the silent second channel
+        if (eo) *eo = hx_mblog(gt->mblog, 7.0e4f);
+        return;
+    }
+    const float *xs = xs2[ch];
     const int base = 480 + 576 * gl + 32 * t + 31;          // newest sample of the slot
     const float *P = xs + (base + (base >> 5) - 526);       // P[526 - pad(off)] = sample of age off
 #define XS(off) P[526 - ((off) + ((off) >> 5))]
@@ -154,25 +161,35 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     float *out = sb + ((long long) (s * 2 + ch) * SG + (g0 + gl + 3)) * 576 + t;
 #pragma unroll
     for (int k = 0; k < 32; k++) out[18 * k] = X[k];
+    {   // slots 2 k (this lane) and 2 k + 1 (the next lane), subband after subband, in the reference's order of additions
+        float sum = 7.0e4f;
+        if (!lsf) {
+#pragma unroll
+            for (int i = 4; i < 18; i++) { const float y1 = __shfl_down(X[i], 1, 64); float x = X[i] * X[i]; sum += x; x = y1 * y1; sum += x; }
+        } else {
+#pragma unroll
+            for (int i = 8; i < 28; i++) { const float y1 = __shfl_down(X[i], 1, 64); float x = X[i] * X[i]; sum += x; x = y1 * y1; sum += x; }
+        }
+        if (eo) *eo = hx_mblog(gt->mblog, sum);
+    }
 }
 
-// energies of subbands 4..17 (MPEG-2 LSF rates: 8..27, detect.c:147-196) per slot pair, as mB.
-// eng index g <-> subband slot g + 2.
+// The energies of eng index 0 (k_polyphase writes the others): from the carried last granule of the previous call,
+// subband slot 2.  total = S * 2 * 9.
 __global__ void k_attack_eng(const float *__restrict__ sb, const HxGlobalTabs *__restrict__ gt,
                              int *__restrict__ eng, int NG, int SG, int total, int lsf)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
-    int k = id % 9, r = id / 9;
-    int g = r % NG, sc = r / NG;
+    int k = id % 9, sc = id / 9;
     const int sb0 = lsf ? 8 : 4, nsbb = lsf ? 20 : 14;
-    const float *y = sb + ((long long) sc * SG + (g + 2)) * 576 + 18 * sb0 + 2 * k;
+    const float *y = sb + ((long long) sc * SG + 2) * 576 + 18 * sb0 + 2 * k;
     float sum = 7.0e4f;
     for (int i = 0; i < nsbb; i++, y += 18) {
         float x = y[0] * y[0]; sum += x;
         x = y[1] * y[1]; sum += x;
     }
-    eng[id] = hx_mblog(gt->mblog, sum);
+    eng[(long long) sc * NG * 9 + k] = hx_mblog(gt->mblog, sum);
 }
 
 // attack metric of one channel at coded step g, for short_flag_prev = 0 and 1
