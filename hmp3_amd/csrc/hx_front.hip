@@ -243,19 +243,37 @@ __global__ void k_blocktype(HxStream *__restrict__ st, const unsigned char *__re
 {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    const unsigned char sel[16] = {0, 1, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 0, 1, 2, 2};
+    // sel[prev type * 4 + short now * 2 + short next] = {0, 1, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 0, 1, 2, 2} as nibbles of a constant
+    const unsigned long long sel = 0x2210222322232210ull;
     HxStream *ss = st + s;
     int prev_next = ss->short_flag_next_prev, prev_bt = ss->bt_prev;
     btprev[s] = (unsigned char) prev_bt;
-    for (int g = 0; g < NG; g++) {
-        int f = flg[(long long) s * NG + g];
-        int next = prev_next ? (f >> 1) & 1 : f & 1;
-        int cur = prev_next;
-        int b = sel[prev_bt * 4 + cur * 2 + next];
-        bt[(long long) s * NG + g] = (unsigned char) b;
+    const unsigned char *fs = flg + (long long) s * NG;
+    unsigned char *bo = bt + (long long) s * NG;
+    auto step = [&](int f) {
+        const int next = prev_next ? (f >> 1) & 1 : f & 1;
+        const int b = (int) ((sel >> (4 * (prev_bt * 4 + prev_next * 2 + next))) & 15);
         prev_bt = b;
         prev_next = next;
-    }
+        return (unsigned) b;
+    };
+    int g = 0;
+    // sixteen granules per load and store (NG is even; the rows of flg / bt are 16-byte aligned when NG % 16 == 0)
+    if ((NG & 15) == 0)
+        for (; g + 16 <= NG; g += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(fs + g);
+            const unsigned in[4] = {v.x, v.y, v.z, v.w};
+            unsigned o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned r = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) r |= step((int) ((in[q] >> (8 * e)) & 255)) << (8 * e);
+                o[q] = r;
+            }
+            *reinterpret_cast<uint4 *>(bo + g) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    for (; g < NG; g++) bo[g] = (unsigned char) step(fs[g]);
     ss->short_flag_next_prev = prev_next;
     ss->bt_prev = prev_bt;
     // roll the energy history: last 32 values of [hist | eng]
@@ -636,20 +654,40 @@ __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const 
     if (lane == 0) {
         const int on = prm[ss->cls].ms_flag, plain = prm[ss->cls].alloc1;    // (the first-generation allocator's measure takes no hysteresis)
         int mem = ss->ms_memory;
-        for (int g = 0; g < NG; g += 2) {
+        auto frame = [&](int b1, int b2, int v1, int v2, int *m1o, int *m2o) {      // one pair of granules; returns the two flags
             int m1 = 0, m2 = 0;
             if (on) {
-                m1 = msbase[g0 + g];
+                m1 = v1;
                 if (plain) { }
-                else if (bt[g0 + g] == 2) mem = 0; else { m1 += mem; mem = (m1 > 0) ? 5000 : -5000; }
-                m2 = msbase[g0 + g + 1];
+                else if (b1 == 2) mem = 0; else { m1 += mem; mem = (m1 > 0) ? 5000 : -5000; }
+                m2 = v2;
                 if (plain) { }
-                else if (bt[g0 + g + 1] == 2) mem = 0; else { m2 += mem; mem = (m2 > 0) ? 5000 : -5000; }
+                else if (b2 == 2) mem = 0; else { m2 += mem; mem = (m2 > 0) ? 5000 : -5000; }
             }
-            msdec[g0 + g] = m1;
-            msdec[g0 + g + 1] = m2;
-            msflag[g0 + g] = (unsigned char) (on && (lsf ? m1 : m1 + m2) >= 0);
-            msflag[g0 + g + 1] = (unsigned char) (on && (lsf ? m2 : m1 + m2) >= 0);
+            *m1o = m1; *m2o = m2;
+            const unsigned f1 = (on && (lsf ? m1 : m1 + m2) >= 0), f2 = (on && (lsf ? m2 : m1 + m2) >= 0);
+            return f1 | (f2 << 8);
+        };
+        int g = 0;
+        // eight granules per round of loads and stores (the rows are 16-byte aligned when NG % 8 == 0)
+        if ((NG & 7) == 0)
+            for (; g + 8 <= NG; g += 8) {
+                const int4 va = *reinterpret_cast<const int4 *>(msbase + g0 + g), vb = *reinterpret_cast<const int4 *>(msbase + g0 + g + 4);
+                const uint2 bb = *reinterpret_cast<const uint2 *>(bt + g0 + g);
+                int4 da, db;
+                const unsigned fa = frame(bb.x & 255, (bb.x >> 8) & 255, va.x, va.y, &da.x, &da.y);
+                const unsigned fb = frame((bb.x >> 16) & 255, bb.x >> 24, va.z, va.w, &da.z, &da.w);
+                const unsigned fc = frame(bb.y & 255, (bb.y >> 8) & 255, vb.x, vb.y, &db.x, &db.y);
+                const unsigned fd = frame((bb.y >> 16) & 255, bb.y >> 24, vb.z, vb.w, &db.z, &db.w);
+                *reinterpret_cast<int4 *>(msdec + g0 + g) = da;
+                *reinterpret_cast<int4 *>(msdec + g0 + g + 4) = db;
+                *reinterpret_cast<uint2 *>(msflag + g0 + g) = make_uint2(fa | (fb << 16), fc | (fd << 16));
+            }
+        for (; g < NG; g += 2) {
+            int m1, m2;
+            const unsigned f = frame(bt[g0 + g], bt[g0 + g + 1], msbase[g0 + g], msbase[g0 + g + 1], &m1, &m2);
+            msdec[g0 + g] = m1; msdec[g0 + g + 1] = m2;
+            msflag[g0 + g] = (unsigned char) (f & 1); msflag[g0 + g + 1] = (unsigned char) (f >> 8);
         }
         ss->ms_memory = mem;
     }
