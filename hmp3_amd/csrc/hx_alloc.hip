@@ -130,6 +130,7 @@ struct alignas(16) AllocLds {
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
     Outbox ob[2];
     const double *pow43;                // HxGlobalTabs::pow43 (global memory)
+    int *big_counter;                   // device counter of line passes that took the double table (tests)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
 #ifdef HX_PROFILE
     unsigned prof[36];                  // 36 slots x 4 bytes keeps the profile build at four workgroups per CU
@@ -304,6 +305,7 @@ __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int
 // path neither registers nor code.  (Bands that are not evaluated quantise to <= 0.)
 __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl)
 {
+    if (LANE == 0) atomicAdd(L.big_counter, 1);
 #pragma unroll 1
     for (int c3 = 0; c3 < 3; c3++) {
         if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;

@@ -106,7 +106,7 @@ struct hx_batch {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr, s_host = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr}, ev_hfront[2] = {nullptr, nullptr};
     long long nhost = 0;
-    int *d_done = nullptr;              // [0] streams retired, [2] streams started by all k_alloc launches of this batch (wrap), [1] gate time-outs
+    int *d_done = nullptr;              // [0] streams retired, [2] streams started by all k_alloc launches of this batch (wrap), [1] gate time-outs, [3] line passes on the double x^(4/3) table
     int resident = 0;                   // allocator workgroups the device holds at once
     long long alloc_launches = 0;
     unsigned long long cfg_hash = 0;    // fingerprint of the resolved configuration classes (checkpoint blobs carry their stream's)
@@ -762,6 +762,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }
     else if (k == "thr") { src = b->d_thr; n = sizeof(float) * S * NG * 128; }
     else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }
+    else if (k == "big_sweeps") { src = b->d_done + 3; n = sizeof(int); }        // gain-search line passes that took the double x^(4/3) table
     else if (k == "bt") { src = b->d_bt; n = S * NG; }
     else if (k == "eng") { src = b->d_eng; n = sizeof(int) * S * 2 * NG * 9; }
     else if (k == "dbg" && b->d_dbg) { src = b->d_dbg; n = sizeof(HxFrameDebug) * S * (NG / 2); }

@@ -105,6 +105,25 @@ def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
     assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=64, short_block_threshold=99999), dict(bitrate=160), dict(vbr_mnr=50), dict(vbr_mnr=120, samprate=48000)],
+                         ids=["cbr128_long", "cbr320", "vbr50", "vbr120_48k"])
+def test_loud_near_mono_material_takes_the_double_table_path(kw):
+    """L = R at full scale: the mid channel quantises beyond the 256-entry float table of ix^(4/3) at low gain steps and the
+    noise terms come from the double-precision table (reference l3math.c:521-535 evaluates gain * pow(ix, 4/3) there)"""
+    sr = kw.get("samprate", 44100)
+    S, F = 8, 40
+    pcm = np.stack([synth.stream_pcm(8100 + i, F, sr=sr, rho=1.0, bursts=wants_bursts(kw)) for i in range(S)])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    b.debug_enable(True)
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    for s in range(S):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    if "bitrate" in kw:     # (the CBR rate loop drives the gain steps low enough; VBR stays above)
+        assert int(b.debug_read("big_sweeps", np.int32, 1)[0]) > 0, "the case does not reach the table's end"
+    b.close()
+
+
 @pytest.mark.parametrize("kw", [dict(bitrate=64), dict(vbr_mnr=60)], ids=["cbr128", "vbr60"])
 def test_packet_variant_matches_oracle(kw):
     """CMp3Enc::L3_audio_encode_Packet: bitstream plus the self-contained packet of every frame"""
