@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
         int2 h1 = make_int2(0, 0);
         int fld = 0;
         const HxFrameOut fo = frm[fr];
+        HxSlot s4[4];
+        {
+            const int nslots = frames_per_stream + HX_SLOTS_EXTRA;
+            const HxSlot *sl0 = slots + (long long) s * nslots;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s4[k] = sl0[min(fo.first_slot + k, nslots - 1)];
+        }
         if (mine) {
             h0 = *reinterpret_cast<const int4 *>(so);
             h1 = reinterpret_cast<const int2 *>(so)[2];
@@ -188,15 +195,24 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
             }
         }
         __syncthreads();
-        // the frame's main data (zero stuffing up to byte_min included) into the pending slots, oldest first
+        // the frame's main data (zero stuffing up to byte_min included) into the pending slots, oldest first; the first
+        // four slots' offsets and sizes are in registers (requested with the segment data), the walk rarely goes further
         const HxSlot *sl = slots + (long long) s * (frames_per_stream + HX_SLOTS_EXTRA);
         unsigned char *o = out + (long long) s * out_stride;
         for (int i = tid; i < fo.bytes; i += 256) {
             const unsigned char v = (i < fo.raw_bytes) ? (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3))) : 0;
-            int q = fo.main_bytes + i, k = fo.first_slot;
-            int cap = sl[k].mf;
-            while (q >= cap) { q -= cap; k++; cap = sl[k].mf; }
-            o[sl[k].off + hdr + q] = v;
+            int q = fo.main_bytes + i, off;
+            if (q < s4[0].mf) off = s4[0].off;
+            else if ((q -= s4[0].mf) < s4[1].mf) off = s4[1].off;
+            else if ((q -= s4[1].mf) < s4[2].mf) off = s4[2].off;
+            else if ((q -= s4[2].mf) < s4[3].mf) off = s4[3].off;
+            else {
+                q -= s4[3].mf;
+                int k = fo.first_slot + 4, cap = sl[k].mf;
+                while (q >= cap) { q -= cap; k++; cap = sl[k].mf; }
+                off = sl[k].off;
+            }
+            o[off + hdr + q] = v;
         }
         if (fo.packet_off >= 0)     // *_Packet outputs: the unpadded main data behind the packet's own header and side info
             for (int i = tid; i < fo.raw_bytes; i += 256) packet[fo.packet_off + i] = (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3)));
