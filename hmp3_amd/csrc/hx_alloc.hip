@@ -59,6 +59,7 @@ struct alignas(16) Outbox {
     HxFrameOut frm;
     HxSlot slot;
     int opos, frm_index, slot_index;    // where they go: header offset in the stream's output, frame and slot number
+    int ring_p0;                        // position of the frame's first slot in the ring of pending frames (r_off / r_mf)
     int has_frame;
 };
 

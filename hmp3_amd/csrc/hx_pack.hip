@@ -159,13 +159,7 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
         int2 h1 = make_int2(0, 0);
         int fld = 0;
         const HxFrameOut fo = frm[fr];
-        HxSlot s4[4];
-        {
-            const int nslots = frames_per_stream + HX_SLOTS_EXTRA;
-            const HxSlot *sl0 = slots + (long long) s * nslots;
-#pragma unroll
-            for (int k = 0; k < 4; k++) s4[k] = sl0[min(fo.first_slot + k, nslots - 1)];
-        }
+        const HxSlot *s4 = fo.near;
         if (mine) {
             h0 = *reinterpret_cast<const int4 *>(so);
             h1 = reinterpret_cast<const int2 *>(so)[2];

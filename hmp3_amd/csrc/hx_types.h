@@ -168,12 +168,14 @@ struct alignas(16) HxSegOut {
     unsigned short sf[40];      // (length << 8) | value of each transmitted scalefactor field
 };
 // One frame: its main data spans the pending slots from first_slot on (the first one has main_bytes bytes in use)
-struct HxFrameOut {
+struct HxSlot { int off, mf; };     // a frame's slot in a stream's output: offset of its header, main-data bytes it holds
+struct alignas(16) HxFrameOut {
     int bytes, raw_bytes;       // main data bytes with / without the zero stuffing up to byte_min
     int first_slot, main_bytes;
     long long packet_off;       // offset of the frame's main data in the packet buffer, -1 = no packet
+    int pad_[2];
+    HxSlot near[4];             // copies of slots first_slot .. first_slot + 3: the packer rarely needs more, and gets them in the record's round trip
 };
-struct HxSlot { int off, mf; };     // a frame's slot in a stream's output: offset of its header, main-data bytes it holds
 #define HX_SLOTS_EXTRA 40           // slots pending from earlier calls (the ring holds 32)
 
 // Arguments of the allocator kernels (k_alloc / k_alloc_lsf), filled by the host runtime.
