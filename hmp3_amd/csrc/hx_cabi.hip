@@ -204,7 +204,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     std::vector<HxStream> st(nstreams);
     for (int s = 0; s < nstreams; s++) hx_stream_reset(&b->params[b->cls_of[s]], b->cls_of[s], &st[s]);
 #define ALLOC(ptr, bytes) do { if (hipMalloc((void **) &(ptr), (size_t) (bytes)) != hipSuccess) { set_err("hipMalloc failed"); hx_batch_destroy(b); return nullptr; } } while (0)
-    ALLOC(b->d_prm, sizeof(HxParams) * b->ncls);
+    ALLOC(b->d_prm, sizeof(HxParams) * b->ncls + 256);        // (k_spec reads a spreading row in 16-byte pieces, up to 60 bytes past its end)
     ALLOC(b->d_gt, sizeof(HxGlobalTabs));
     ALLOC(b->d_st, sizeof(HxStream) * S);
     ALLOC(b->d_sb, sizeof(float) * S * 2 * (NG + 3) * 576);
@@ -446,7 +446,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
            b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
     LAUNCH(k_blocktype, dim3((S + 63) / 64), dim3(64), q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
-    LAUNCH(k_spec, dim3((unsigned) ((long long) S * NG)), dim3(64), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
+    LAUNCH(k_spec, dim3((unsigned) ((long long) S * nframes)), dim3(128), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
            x_etab, x_thr, x_msbase, NG, SG);
     // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
     // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first

@@ -367,106 +367,142 @@ __device__ __forceinline__ void mdct_kernel(const HxParams *p, const float *pre,
 // reading, so the stored subband samples stay un-inverted; the alias butterflies exchange 8
 // values with each neighbour lane.
 
-// Psychoacoustic model of one channel; x = the channel's 576 lines (LDS).  Outputs etab (energy +
-// absolute threshold) and thr = a * stab (threshold before pre-echo control); for a short granule
-// thr holds mask[12*w + sfb] and etab is zero.
-__device__ __forceinline__ void psy_unit(const float *x, const HxParams *p, const HxGlobalTabs *gt, float *etab_out,
-                                         float *thr_out, bool is_short, float *xtab, float (*es)[64])
+// (hand-overs inside a wave need no workgroup barrier: its LDS operations execute in order)
+#define FE_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// The lookup tables every psy / metric step gathers from (mB logarithm, mB exponential): staged in LDS once per
+// workgroup.  Gathers from global memory queue behind the kernel's own streaming loads and stores in the vector
+// memory path - a dozen dependent ones per channel were three quarters of this kernel's time.
+struct SpecTabs { int mblog[256]; float mbexp_lo[256], mbexp_hi[256]; };
+
+// Psychoacoustic model of a short granule's channel (reference emap.c:61-93, spdsmr.c:64-107): per-window partition
+// energies, then mask[w][sfb] = spread(2 sfb partitions); pre-echo control happens in the allocator.  x = the
+// channel's 576 lines (LDS); thr gets mask[12*w + sfb], etab zeros.  Short granules are rare: table reads from global memory.
+__device__ __noinline__ void psy_short(const float *x, const HxParams *p, float *etab_out, float *thr_out, float (*es)[64])
 {
-    const int lane = threadIdx.x;
-    if (is_short) {
-        // short block (reference emap.c:61-93, spdsmr.c:64-107): per-window partition energies,
-        // then mask[w][sfb] = spread(2 sfb partitions); pre-echo control happens in the allocator
-        const HxPsyTab *ps = &p->psyS;
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-        if (lane < ps->npart_e) {
-            int i0 = ps->pstart[lane], n = ps->nsum[lane];
-            for (int k = 0; k < n; k++) {
-                s0 += x[i0 + k] * x[i0 + k];
-                s1 += x[192 + i0 + k] * x[192 + i0 + k];
-                s2 += x[384 + i0 + k] * x[384 + i0 + k];
-            }
+    const int lane = threadIdx.x & 63;
+    const HxPsyTab *ps = &p->psyS;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (lane < ps->npart_e) {
+        int i0 = ps->pstart[lane], n = ps->nsum[lane];
+        for (int k = 0; k < n; k++) {
+            s0 += x[i0 + k] * x[i0 + k];
+            s1 += x[192 + i0 + k] * x[192 + i0 + k];
+            s2 += x[384 + i0 + k] * x[384 + i0 + k];
         }
-        es[0][lane] = s0; es[1][lane] = s1; es[2][lane] = s2;
-        __syncthreads();
-        float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
-        if (lane < 12 && 2 * lane < ps->npart) {
-            float a[3] = {0.5f, 0.5f, 0.5f}, b[3] = {0.5f, 0.5f, 0.5f};
-            int i = 2 * lane, q = ps->off[i], n = ps->cnt[i], r = ps->row[i];
-            for (int j = 0; j < n; j++)
-                for (int w = 0; w < 3; w++) a[w] += ps->w[r + j] * es[w][q + j];
-            q = ps->off[i + 1]; n = ps->cnt[i + 1]; r = ps->row[i + 1];
-            for (int j = 0; j < n; j++)
-                for (int w = 0; w < 3; w++) b[w] += ps->w[r + j] * es[w][q + j];
-            m0 = a[0] + b[0]; m1 = a[1] + b[1]; m2 = a[2] + b[2];
-        }
-        etab_out[lane] = 0.0f;
-        // thr layout for short granules: [12*w + sfb]
-        if (lane < 12) { thr_out[lane] = m0; thr_out[12 + lane] = m1; thr_out[24 + lane] = m2; }
-        else if (lane >= 36) thr_out[lane] = 0.0f;
-        __syncthreads();
-        return;
     }
+    es[0][lane] = s0; es[1][lane] = s1; es[2][lane] = s2;
+    FE_WAVE_SYNC();
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    if (lane < 12 && 2 * lane < ps->npart) {
+        float a[3] = {0.5f, 0.5f, 0.5f}, b[3] = {0.5f, 0.5f, 0.5f};
+        int i = 2 * lane, q = ps->off[i], n = ps->cnt[i], r = ps->row[i];
+        for (int j = 0; j < n; j++)
+            for (int w = 0; w < 3; w++) a[w] += ps->w[r + j] * es[w][q + j];
+        q = ps->off[i + 1]; n = ps->cnt[i + 1]; r = ps->row[i + 1];
+        for (int j = 0; j < n; j++)
+            for (int w = 0; w < 3; w++) b[w] += ps->w[r + j] * es[w][q + j];
+        m0 = a[0] + b[0]; m1 = a[1] + b[1]; m2 = a[2] + b[2];
+    }
+    etab_out[lane] = 0.0f;
+    // thr layout for short granules: [12*w + sfb]
+    if (lane < 12) { thr_out[lane] = m0; thr_out[12 + lane] = m1; thr_out[24 + lane] = m2; }
+    else if (lane >= 36) thr_out[lane] = 0.0f;
+    FE_WAVE_SYNC();
+}
+
+// Psychoacoustic model of a long granule, both channels in one pass (lane = partition): partition energies, spreading
+// (reference emap.c / spdsmr.c:185-262), signal-to-noise statistics and the threshold scale.  The lane's table entries
+// (pc: first line, lines, spreading row start / length / first source, absolute threshold) were read at the start of
+// the kernel; the spreading weights of a row, the same for both channels, are read once for the two and eight at a
+// time; per channel the order of operations is the reference's.  Outputs etab (energy + absolute threshold) and
+// thr = a * stab (threshold before pre-echo control).
+struct PsyLane { int i0, nsum, off, cnt, row; float wabs; };
+__device__ __forceinline__ void psy_long2(const float *xl, const HxParams *p, const SpecTabs &T, const PsyLane &pc,
+                                          float *etab_out, float *thr_out, float (*xtab)[64])
+{
+    const int lane = threadIdx.x & 63;
     const HxPsyTab *pt = &p->psyL;
     const float *w = pt->w;
     const float alpha = 0.30f;
     const int npart = pt->npart, npart2 = (npart + 1) & (~1);
-    float e = 0.0f;
+    float e[2] = {0.0f, 0.0f};
     if (lane < pt->npart_e) {
-        int i0 = pt->pstart[lane], n = pt->nsum[lane];
-        float sum = 0.0f;
-        for (int k = 0; k < n; k++) sum += x[i0 + k] * x[i0 + k];
-        e = sum;
+        float s0 = 0.0f, s1 = 0.0f;
+        const float *xa = xl + pc.i0, *xb = xl + 576 + pc.i0;
+        for (int k = 0; k < pc.nsum; k++) { s0 += xa[k] * xa[k]; s1 += xb[k] * xb[k]; }
+        e[0] = s0; e[1] = s1;
     }
-    float et = 0.0f;
-    int mbe = 0;
+    float et[2] = {0.0f, 0.0f};
+    int mbe[2] = {0, 0};
     if (lane < npart2) {
-        et = w[lane] + e;
-        mbe = hx_mblog(gt->mblog, et);
-        xtab[lane] = hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, (int) (alpha * mbe));
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            et[c] = pc.wabs + e[c];
+            mbe[c] = hx_mblog(T.mblog, et[c]);
+            xtab[c][lane] = hx_mbexp(T.mbexp_lo, T.mbexp_hi, (int) (alpha * mbe[c]));
+        }
     }
-    __syncthreads();
-    float stab = 0.0f;
-    int snr = 0;
+    FE_WAVE_SYNC();
+    float sacc[2] = {0.1f, 0.1f};
     if (lane < npart) {
-        float sacc = 0.1f;
-        int q = pt->off[lane], n = pt->cnt[lane], r = pt->row[lane];
-        for (int j = 0; j < n; j++) sacc += w[r + j] * xtab[q + j];
-        sacc = (0.03f * 0.1f * 0.35f) * hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, (int) ((1.0f / alpha) * hx_mblog(gt->mblog, sacc))) + w[lane];
-        stab = sacc;
-        snr = mbe - hx_mblog(gt->mblog, w[lane] + sacc);
+        const float *wr = w + pc.row, *xa = xtab[0] + pc.off, *xb = xtab[1] + pc.off;
+        const int n = pc.cnt;
+        // 16 weights per round, four 16-byte reads in flight (rows start at any word; what a read takes in beyond the
+        // row's end - the next row, or past the table the struct's following members - is not used)
+        for (int j0 = 0; j0 < n; j0 += 16) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const f4u t = *reinterpret_cast<const f4u *>(wr + j0 + 4 * u);
+                wv[4 * u] = t.x; wv[4 * u + 1] = t.y; wv[4 * u + 2] = t.z; wv[4 * u + 3] = t.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (j0 + u < n) { sacc[0] += wv[u] * xa[j0 + u]; sacc[1] += wv[u] * xb[j0 + u]; }
+        }
     }
-    int prev = __shfl_up(snr, 1, 64);
-    if (lane == 0) prev = 0;
-    const bool in = lane < npart;
-    int nsnr = hx_wave_sum((in && snr > 0) ? 1 : 0);
-    int totsnr = hx_wave_sum(in ? max(-200, snr) : 0);
-    int snrvar = hx_wave_sum(in ? abs(snr - prev) : 0);
-    int d = 0;
-    if (nsnr > 0) {
-        int d0 = hx_round(1.3f * (totsnr / npart) - 850);
-        int itmp = snrvar / npart;
-        int dv = min(500 - itmp, 0);
-        d = d0 + dv;
-        d = max(d, -2000);
-        d = min(d, 600);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float stab = 0.0f;
+        int snr = 0;
+        if (lane < npart) {
+            const float sa = (0.03f * 0.1f * 0.35f) * hx_mbexp(T.mbexp_lo, T.mbexp_hi, (int) ((1.0f / alpha) * hx_mblog(T.mblog, sacc[c]))) + pc.wabs;
+            stab = sa;
+            snr = mbe[c] - hx_mblog(T.mblog, pc.wabs + sa);
+        }
+        int prev = __shfl_up(snr, 1, 64);
+        if (lane == 0) prev = 0;
+        const bool in = lane < npart;
+        int nsnr = hx_wave_sum((in && snr > 0) ? 1 : 0);
+        int totsnr = hx_wave_sum(in ? max(-200, snr) : 0);
+        int snrvar = hx_wave_sum(in ? abs(snr - prev) : 0);
+        int d = 0;
+        if (nsnr > 0) {
+            int d0 = hx_round(1.3f * (totsnr / npart) - 850);
+            int itmp = snrvar / npart;
+            int dv = min(500 - itmp, 0);
+            d = d0 + dv;
+            d = max(d, -2000);
+            d = min(d, 600);
+        }
+        d += 300;
+        int dm0 = (300 - d) >> 4;
+        int m = lane >> 1;
+        int dm = max(dm0 * max(m - 13, 0), 0);
+        float a = hx_mbexp(T.mbexp_lo, T.mbexp_hi, d + dm);
+        etab_out[64 * c + lane] = (lane < npart2) ? et[c] : 0.0f;
+        thr_out[64 * c + lane] = (lane < npart2) ? a * stab : 0.0f;
     }
-    d += 300;
-    int dm0 = (300 - d) >> 4;
-    int m = lane >> 1;
-    int dm = max(dm0 * max(m - 13, 0), 0);
-    float a = hx_mbexp(gt->mbexp_lo, gt->mbexp_hi, d + dm);
-    etab_out[lane] = (lane < npart2) ? et : 0.0f;
-    thr_out[lane] = (lane < npart2) ? a * stab : 0.0f;
-    __syncthreads();        // xtab is reused by the next channel
+    FE_WAVE_SYNC();
 }
 
 // M/S decision metric before hysteresis: lane = scalefactor band (reference bitallo3.cpp:695-742);
 // x0 / x1 = the two channels' lines (LDS)
-__device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, const HxParams *p, const HxGlobalTabs *gt,
-                                              int *out, bool is_short)
+__device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, const HxParams *p, const int *t_mblog,
+                                              int *out, bool is_short, int sb_start, int sb_n)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     int v = 0;
     if (is_short) {         // short block (reference bitallos.cpp:377-416): lane = (window, sfb)
         const int w = lane >> 4, i = lane & 15;
@@ -506,7 +542,7 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
         return;
     }
     if (lane < p->nsf[0]) {
-        int k = p->startBand_l[lane], n = p->nBand_l[lane];
+        int k = sb_start, n = sb_n;
         float el = 100.0f, er = 100.0f, t = 0.0f;
         for (int j = 0; j < n; j++, k++) {
             float a = x0[k] * x0[k], b = x1[k] * x1[k], c = x0[k] * x1[k];
@@ -517,8 +553,8 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
         t = t + t;
         es = es + t;
         ed = ed - t;
-        int mblr = hx_mblog(gt->mblog, el + er) - hx_mblog(gt->mblog, el > er ? el : er);
-        int mbsd = hx_mblog(gt->mblog, es + ed) - hx_mblog(gt->mblog, es > ed ? es : ed);
+        int mblr = hx_mblog(t_mblog, el + er) - hx_mblog(t_mblog, el > er ? el : er);
+        int mbsd = hx_mblog(t_mblog, es + ed) - hx_mblog(t_mblog, es > ed ? es : ed);
         int psd = max(75 - abs(mblr - 120), 0);
         mbsd = min(mbsd, (mbsd >> 1) + 120);
         mbsd += psd;
@@ -528,7 +564,7 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
     if (lane == 0) *out = v;
 }
 
-__global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const HxStream *__restrict__ st,
+__global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, const HxStream *__restrict__ st,
                                              const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
                                              const unsigned char *__restrict__ bt,
                                              float *__restrict__ xr, float *__restrict__ etab_out, float *__restrict__ thr_out,
@@ -536,13 +572,23 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
 {
     // in: [ch][S[g-3] | S[g-2]][576] subband samples; the first 2 x 576 floats are reused as the
     // spectrum [ch][576] once every lane holds its inputs in registers
-    __shared__ __attribute__((aligned(16))) float in[2][2][576];
-    __shared__ float xtab[64];
-    __shared__ float es[3][64];
-    const int lane = threadIdx.x, sbnd = lane & 31, ch = lane >> 5;
-    const long long sg = blockIdx.x;            // (s, g)
+    // two granules per workgroup, one wavefront each, independent of each other but for the lookup tables they share
+    __shared__ __attribute__((aligned(16))) float in_s[2][2][2][576];
+    __shared__ float xtab_s[2][2][64];
+    __shared__ float es_s[2][3][64];
+    __shared__ SpecTabs T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sbnd = lane & 31, ch = lane >> 5;
+    for (int i = threadIdx.x; i < 256; i += 128) { T.mblog[i] = gt->mblog[i]; T.mbexp_lo[i] = gt->mbexp_lo[i]; T.mbexp_hi[i] = gt->mbexp_hi[i]; }
+    const long long sg = (long long) blockIdx.x * 2 + wv;           // (s, g); S * NG is even
     const int g = (int) (sg % NG), s = (int) (sg / NG);
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);      // wave-uniform: table reads become scalar loads
+    float (*in)[2][576] = in_s[wv];
+    // this lane's entries of the psy and band tables: requested now, needed after the transform
+    PsyLane pc;
+    pc.i0 = p->psyL.pstart[lane]; pc.nsum = p->psyL.nsum[lane]; pc.off = p->psyL.off[lane]; pc.cnt = p->psyL.cnt[lane];
+    pc.row = p->psyL.row[lane]; pc.wabs = p->psyL.w[lane];
+    const int sb_start = p->startBand_l[min(lane, 22)], sb_n = p->nBand_l[min(lane, 21)];
+    __syncthreads();        // the tables (the only workgroup barrier: from here on each wave is on its own)
     const int nsb = p->nsb_ms0;
     const int btype = bt[sg];
     {   // 2 x 1152 contiguous floats per channel, 16 bytes per lane and load
@@ -555,7 +601,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
 #pragma unroll
         for (int k = 0; k < 9; k++) reinterpret_cast<float4 *>(&in[0][0][0])[lane + 64 * k] = v[k];
     }
-    __syncthreads();
+    FE_WAVE_SYNC();
     const float *x1 = &in[ch][0][sbnd * 18];    // S[g-3]
     const float *x2 = &in[ch][1][sbnd * 18];    // S[g-2]
     float y[18], f[18];
@@ -569,7 +615,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
             if (inv && (i & 1)) { a = -a; b = -b; }
             p1[i] = a; p2[i] = b;
         }
-        __syncthreads();                        // everyone has its inputs: `in` may be overwritten
+        FE_WAVE_SYNC();                         // everyone has its inputs: `in` may be overwritten
         if (!act) {
 #pragma unroll
             for (int i = 0; i < 18; i++) y[i] = 0.0f;
@@ -624,7 +670,7 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
 #pragma unroll
             for (int k = 0; k < 6; k++) o[192 * w + k] = y[6 * w + k];
     }
-    __syncthreads();
+    FE_WAVE_SYNC();
     {   // spectrum to global memory, 16 bytes per lane and store
         float4 *dst = reinterpret_cast<float4 *>(xr + sg * 1152);
 #pragma unroll
@@ -634,9 +680,12 @@ __global__ __launch_bounds__(64) void k_spec(const float *__restrict__ sb, const
             if (e < 288) __builtin_nontemporal_store(reinterpret_cast<const f4v *>(xl)[e], reinterpret_cast<f4v *>(dst) + e);     // read once, a kernel later
         }
     }
-    psy_unit(xl, p, gt, etab_out + sg * 128, thr_out + sg * 128, btype == 2, xtab, es);
-    psy_unit(xl + 576, p, gt, etab_out + sg * 128 + 64, thr_out + sg * 128 + 64, btype == 2, xtab, es);
-    msmetric_unit(xl, xl + 576, p, gt, msbase + sg, btype == 2);
+    if (btype != 2) psy_long2(xl, p, T, pc, etab_out + sg * 128, thr_out + sg * 128, xtab_s[wv]);
+    else {
+        psy_short(xl, p, etab_out + sg * 128, thr_out + sg * 128, es_s[wv]);
+        psy_short(xl + 576, p, etab_out + sg * 128 + 64, thr_out + sg * 128 + 64, es_s[wv]);
+    }
+    msmetric_unit(xl, xl + 576, p, T.mblog, msbase + sg, btype == 2, sb_start, sb_n);
 }
 
 // K5a: the frame's stereo decision (joint-stereo streams), serial per stream over its granules, and the hand-over
