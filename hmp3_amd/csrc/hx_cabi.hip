@@ -32,6 +32,7 @@ __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTa
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
                        int frames_per_stream, int NG, int lsf, long long nframes_total);
 __global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes);
+__global__ void k_order(const unsigned *dur, int *order, int S);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
@@ -106,6 +107,8 @@ struct hx_batch {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr, s_host = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr}, ev_hfront[2] = {nullptr, nullptr};
     long long nhost = 0;
+    unsigned *d_dur = nullptr;          // [S] duration of each stream's allocator workgroup in the last launch
+    int *d_order = nullptr;             // [S] workgroup -> stream for the next launch (used when the batch exceeds what the chip holds at once)
     int *d_done = nullptr;              // [0] streams retired, [2] streams started by all k_alloc launches of this batch (wrap), [1] gate time-outs, [3] line passes on the double x^(4/3) table
     int resident = 0;                   // allocator workgroups the device holds at once
     long long alloc_launches = 0;
@@ -114,6 +117,7 @@ struct hx_batch {
     // Not 100: the gate's own wavefront holds register space on one SIMD, so the last allocator workgroup of a full
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
+    int lpt = 1;                        // longest-first workgroup order: 1 = for batches beyond the resident set, 0 = never, 2 = always (HMP3AMD_LPT; tests)
 };
 
 extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
@@ -137,7 +141,7 @@ extern "C" void hx_batch_destroy(hx_batch *b)
                     b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done,
                     b->d_x34, b->d_thrprev, b->d_xrdbg, b->d_sgn, b->d_msflag, b->d_band, b->d_msdec,
                     b->d_x342, b->d_thrprev2, b->d_sgn2, b->d_msflag2, b->d_band2, b->d_msdec2,
-                    b->d_ixq, b->d_seg, b->d_frm, b->d_slots};
+                    b->d_ixq, b->d_seg, b->d_frm, b->d_slots, b->d_dur, b->d_order};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 2; i++) {
         if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]);
@@ -228,6 +232,10 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_btprev, S);
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
+    if (const char *e = getenv("HMP3AMD_LPT")) b->lpt = atoi(e);
+    ALLOC(b->d_dur, sizeof(unsigned) * S);
+    ALLOC(b->d_order, sizeof(int) * S);
+    HIPCHKN(hipMemset(b->d_dur, 0, sizeof(unsigned) * S));
     ALLOC(b->d_done, 4 * sizeof(int));
     HIPCHKN(hipMemset(b->d_done, 0, 4 * sizeof(int)));
     {
@@ -466,6 +474,12 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
     a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
     a.done_counter = b->d_done;
+    a.dur = b->d_dur;
+    a.order = nullptr;
+    if ((S > b->resident && b->lpt) || b->lpt == 2) {       // more streams than resident workgroups: longest first
+        LAUNCH(k_order, dim3(1), dim3(1024), qa, (const unsigned *) b->d_dur, b->d_order, S);
+        a.order = b->d_order;
+    }
     a.x34 = x_x34; a.sgn = x_sgn; a.band = x_band; a.msflag = x_msflag; a.msdec = x_msdec; a.thrprev = x_thrprev;
     a.ixq = b->d_ixq; a.sgn_w = x_sgn; a.seg = b->d_seg; a.frm = b->d_frm; a.slots = b->d_slots;
     b->alloc_launches++;

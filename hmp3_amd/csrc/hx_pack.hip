@@ -225,3 +225,27 @@ __global__ __launch_bounds__(64) void k_pack_carry(HxStream *__restrict__ st, co
     const int n = ss->main_p1;
     for (int i = threadIdx.x; i < n; i += 64) ss->main_buf[i] = src[i];
 }
+
+// Workgroup order of the next allocator launch: streams by this launch's duration, longest first (a counting sort on
+// 1024 duration classes; the order within a class does not matter).  One workgroup.
+__global__ __launch_bounds__(1024) void k_order(const unsigned *__restrict__ dur, int *__restrict__ order, int S)
+{
+    __shared__ unsigned hist[1024];
+    __shared__ unsigned lo, hi;
+    const int tid = threadIdx.x;
+    if (tid == 0) { lo = 0xFFFFFFFFu; hi = 0; }
+    hist[tid] = 0;
+    __syncthreads();
+    unsigned mn = 0xFFFFFFFFu, mx = 0;
+    for (int i = tid; i < S; i += 1024) { const unsigned d = dur[i]; mn = min(mn, d); mx = max(mx, d); }
+    atomicMin(&lo, mn);
+    atomicMax(&hi, mx);
+    __syncthreads();
+    const unsigned base = lo;
+    const unsigned long long range = (unsigned long long) (hi - lo) + 1;
+    for (int i = tid; i < S; i += 1024) atomicAdd(&hist[1023 - (unsigned) (((unsigned long long) (dur[i] - base) * 1024) / range)], 1u);
+    __syncthreads();
+    if (tid == 0) { unsigned acc = 0; for (int b = 0; b < 1024; b++) { const unsigned c = hist[b]; hist[b] = acc; acc += c; } }
+    __syncthreads();
+    for (int i = tid; i < S; i += 1024) order[atomicAdd(&hist[1023 - (unsigned) (((unsigned long long) (dur[i] - base) * 1024) / range)], 1u)] = i;
+}

@@ -199,6 +199,8 @@ struct AllocArgs {
     long long packet_stride;
     int *packet_bytes;          // [S][F]
     int *frame_stats;           // optional [S][F][2]: frames / bytes emitted by the stream after each input frame
+    const int *order;           // workgroup -> stream (longest-running first, from the previous call's durations), or null = identity
+    unsigned *dur;              // [S] this call's duration of each stream's workgroup, 100 MHz ticks
     int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter)
     // from k_msscan / k_prep (hx_front.hip); xr holds the coded magnitudes for long-block granules
     const float *x34;           // [S][NG][2][576] x^(3/4) of the magnitudes (long-block granules)

@@ -140,3 +140,30 @@ def test_cli_streams_from_a_pipe_with_bounded_buffers(name, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-400:]
     assert b"ec->samprate" in r.stderr            # -EC prints the settings in use
     assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_longest_first_workgroup_order_changes_nothing_in_the_output(monkeypatch):
+    """Batches beyond what the chip holds at once start their allocator workgroups by the previous call's stream durations,
+    longest first (hx_cabi.hip k_order); forced here on a small batch (HMP3AMD_LPT=2), three calls so that the order is a
+    real permutation, against the oracle"""
+    import numpy as np
+    from hmp3_amd import api, synth
+    from oracle import oracle as O
+    monkeypatch.setenv("HMP3AMD_LPT", "2")
+    S, F, calls = 24, 12, 3
+    rhos = [0.7, 0.0, 1.0, 0.3]
+    pcm = np.stack([synth.stream_pcm(7700 + i, F * calls, rho=rhos[i % 4], bursts=(i % 3 == 0)) for i in range(S)])
+    kw = dict(bitrate=64)
+    b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    got = [b"" for _ in range(S)]
+    for c in range(calls):
+        out = b.encode_host(np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152]))
+        for s in range(S):
+            got[s] += out[s]
+    assert b.status() == 0
+    for s in range(S):
+        enc = O.OracleEncoder(O.default_control(**kw))
+        want = b"".join(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F * calls))
+        assert got[s] == want, "stream %d" % s
+    b.close()
