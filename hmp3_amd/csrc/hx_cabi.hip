@@ -26,7 +26,7 @@ __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm,
 __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf, int nchan);
 __global__ void k_msscan(HxStream *st, const HxParams *prm, const int *msbase, const unsigned char *bt, unsigned char *msflag, int *msdec,
                          const float *thr, float *thrprev, int NG, int lsf);
-__global__ void k_prep(float *xr, float *x34o, unsigned char *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
+__global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned char *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
                        const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG, long long nunits);
 __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned char *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
@@ -458,9 +458,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
            x_etab, x_thr, x_msbase, NG, SG);
     // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
     // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
-    if (b->debug && b->d_xrdbg) HIPCHK(hipMemcpyAsync(b->d_xrdbg, x_xr, sizeof(float) * (size_t) S * NG * 1152, hipMemcpyDeviceToDevice, q));
     LAUNCH(k_msscan, dim3(S), dim3(64), q, b->d_st, b->d_prm, x_msbase, x_bt, x_msflag, x_msdec, x_thr, x_thrprev, NG, b->lsf);
-    LAUNCH(k_prep, dim3((unsigned) (((long long) S * NG + 3) / 4)), dim3(256), q, x_xr, x_x34, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
+    LAUNCH(k_prep, dim3((unsigned) (((long long) S * NG + 3) / 4)), dim3(256), q, (const float *) x_xr, (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, x_x34, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
            x_etab, x_thr, x_thrprev, NG, (long long) S * NG);
     // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
     LAUNCH(k_carry, dim3(S * 2), dim3(256), q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
@@ -764,8 +763,8 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     long long n = 0;
     std::string k(name);
     if (k == "sb") { src = b->d_sb; n = sizeof(float) * S * 2 * (2LL * b->maxF + 3) * 576; }
-    else if (k == "xr") { src = b->d_xrdbg ? b->d_xrdbg : b->d_xr; n = sizeof(float) * S * NG * 1152; }     // the spectrum before k_prep (debug tap)
-    else if (k == "xmag") { src = b->d_xr; n = sizeof(float) * S * NG * 1152; }
+    else if (k == "xr") { src = b->d_xr; n = sizeof(float) * S * NG * 1152; }       // the spectrum
+    else if (k == "xmag") { src = b->d_xrdbg; n = sizeof(float) * S * NG * 1152; }  // the magnitudes k_prep works on (written in debug mode only)
     else if (k == "x34") { src = b->d_x34; n = sizeof(float) * S * NG * 1152; }
     else if (k == "band") { src = b->d_band; n = sizeof(HxBandPrep) * S * NG; }
     else if (k == "msflag") { src = b->d_msflag; n = S * NG; }

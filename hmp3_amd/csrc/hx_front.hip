@@ -760,10 +760,9 @@ __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const 
 // is coded in (L / R, or M = L + R, S = L - R: reference l3math.c:449-470,905-930), band energies in line order
 // (bitallo3.cpp:816-864,902-985), x^(3/4) of every line with the band maxima and the zero-gain steps
 // (:878-896, pow34.c:132-186), and the masking thresholds after pre-echo control (spdsmr.c:275-318).  The
-// magnitudes replace the spectrum in place; short-block granules are left as they are (their allocator starts
-// from the raw spectrum).
+// short-block granules are skipped (their allocator starts from the raw spectrum).
 #define PREP_GPB 4      // granules (wavefronts) per workgroup: they share one copy of the lookup tables
-__global__ __launch_bounds__(64 * PREP_GPB) void k_prep(float *__restrict__ xr, float *__restrict__ x34o, unsigned char *__restrict__ sgn,
+__global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict__ xr, float *__restrict__ xmag_dbg, float *__restrict__ x34o, unsigned char *__restrict__ sgn,
                                              HxBandPrep *__restrict__ band, const HxStream *__restrict__ st,
                                              const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
                                              const unsigned char *__restrict__ bt, const unsigned char *__restrict__ msflag,
@@ -800,7 +799,7 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(float *__restrict__ xr, 
     const int nl_p0 = ms ? p->nbmax2[0] : p->nbmax3[0], nl_p1 = two ? (ms ? p->nbmax2[1] : p->nbmax3[1]) : 0;
     const int nb_e0 = ms ? nsf0 : p->nsf3[0], nb_e1 = ms ? nsf0 : (two ? p->nsf3[1] : 0);
     const int nb_z0 = ms ? p->nsf2[0] : p->nsf3[0], nb_z1 = two ? (ms ? p->nsf2[1] : p->nsf3[1]) : 0;
-    float *x = xr + unit * 1152;
+    const float *x = xr + unit * 1152;
     float (*sqw)[576] = sq[wv];
     // lane l owns lines 4 (l + 64 k) .. + 3 of both channels, k = 0..2 (144 groups of four per channel)
     float a0[3][4], a1[3][4];           // magnitudes in the coded representation
@@ -912,15 +911,20 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(float *__restrict__ xr, 
         bp->xsxx[ch][i] = e_lr; bp->x34max[ch][i] = xm; bp->n0[ch][i] = n0; bp->n0ms[ch][i] = n0ms;
         bp->gzero[ch][i] = gz; bp->maskmb[ch][i] = mmb;
     }
-    {   // magnitudes over the spectrum, x^(3/4) and signs to their buffers, straight from the owning lanes
-        float4 *dx = reinterpret_cast<float4 *>(x), *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);
+    {   // x^(3/4) and signs to their buffers, straight from the owning lanes.  The magnitudes themselves are not stored:
+        // the allocator's helper wave forms them again from the spectrum it fetches (two operations per line, no
+        // rounding) - cheaper than 2.4 GB of stores and as many loads per launch.  (xmag_dbg: the tests' tap.)
+        float4 *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);
         unsigned *ds = reinterpret_cast<unsigned *>(sgn + unit * 1152);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int e = lane + 64 * k;
             if (e < 144) {
-                dx[e] = make_float4(a0[k][0], a0[k][1], a0[k][2], a0[k][3]);
-                dx[144 + e] = make_float4(a1[k][0], a1[k][1], a1[k][2], a1[k][3]);
+                if (xmag_dbg) {
+                    float4 *dx = reinterpret_cast<float4 *>(xmag_dbg + unit * 1152);
+                    dx[e] = make_float4(a0[k][0], a0[k][1], a0[k][2], a0[k][3]);
+                    dx[144 + e] = make_float4(a1[k][0], a1[k][1], a1[k][2], a1[k][3]);
+                }
                 dq[e] = make_float4(q0[k][0], q0[k][1], q0[k][2], q0[k][3]);
                 dq[144 + e] = make_float4(q1[k][0], q1[k][1], q1[k][2], q1[k][3]);
                 ds[e] = s0[k];
