@@ -31,7 +31,8 @@ __global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned c
 __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned char *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
                        int frames_per_stream, int NG, int lsf, long long nframes_total);
-__global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes);
+__global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes, const int *carry_len);
+__global__ void k_pack_pre(const HxStream *st, unsigned char *out, long long out_stride, const int *pre_len);
 __global__ void k_order(const unsigned *dur, int *order, int S);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
@@ -67,10 +68,12 @@ struct hx_batch {
     HxBandPrep *d_band = nullptr;
     int *d_msdec = nullptr;
     // k_alloc -> k_pack: quantised lines, segment and frame records, slot lists
-    short *d_ixq = nullptr;
-    HxSegOut *d_seg = nullptr;
-    HxFrameOut *d_frm = nullptr;
-    HxSlot *d_slots = nullptr;
+    short *d_ixq = nullptr, *d_ixq2 = nullptr;          // (second set: the submit path, where call n + 1 is allocated while call n is packed)
+    HxSegOut *d_seg = nullptr, *d_seg2 = nullptr;
+    HxFrameOut *d_frm = nullptr, *d_frm2 = nullptr;
+    HxSlot *d_slots = nullptr, *d_slots2 = nullptr;
+    unsigned char *d_sgn3 = nullptr;                    // third set of the signs: written by the front end of call n + 2 while call n is packed
+    int *d_lens = nullptr;                              // [2 sets][pre_len | carry_len][S]
     int *frame_stats = nullptr;         // caller's per-frame counters (device), optional
     unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
     float *d_pcmf = nullptr;            // DC-blocked input, only when a stream uses filter_select = 1
@@ -97,8 +100,13 @@ struct hx_batch {
     int *d_msbase2 = nullptr, *d_msdec2 = nullptr;
     unsigned char *d_bt2 = nullptr, *d_btprev2 = nullptr, *d_sgn2 = nullptr, *d_msflag2 = nullptr;
     HxBandPrep *d_band2 = nullptr;
-    hipStream_t s_front = nullptr, s_alloc = nullptr;
-    hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};
+    hipStream_t s_front = nullptr, s_alloc = nullptr, s_pack = nullptr;
+    hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};     // ev_alloc: a submit's packing is done (everything is)
+    hipEvent_t ev_k6[2] = {nullptr, nullptr};           // a submit's allocator launch is done
+    hipEvent_t ev_sgn[3] = {nullptr, nullptr, nullptr}; // the packing that read this set of signs is done
+    // the packing of the latest device-buffer submit, not enqueued yet: it goes out behind the next submit's allocator launch
+    // (released by a gate like the front end, into that launch's tail), or ungated at the next wait / plain call
+    struct PackJob { bool pending = false; unsigned char *d_out = nullptr; long long out_stride = 0; int *d_out_bytes = nullptr; int nframes = 0, set = 0, sset = 0; } pack_job;
     long long nsubmit = 0;
     bool inflight = false;
     // hx_batch_submit_*_host: device staging for two calls in flight and the copy streams
@@ -131,17 +139,21 @@ extern "C" int hx_device_count(void)
 
 extern "C" void hx_default_control(HX_E_CONTROL *ec) { hx_host_default_control((HxControl *) ec); }
 
+static int flush_pack(hx_batch *b, long long gate_base);
+
 extern "C" void hx_batch_destroy(hx_batch *b)
 {
     if (!b) return;
     hipSetDevice(b->device);
+    if (b->s_pack) flush_pack(b, -1);
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
                     b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
                     b->d_xr2, b->d_etab2, b->d_thr2, b->d_msbase2, b->d_bt2, b->d_btprev2, b->d_done,
                     b->d_x34, b->d_thrprev, b->d_xrdbg, b->d_sgn, b->d_msflag, b->d_band, b->d_msdec,
                     b->d_x342, b->d_thrprev2, b->d_sgn2, b->d_msflag2, b->d_band2, b->d_msdec2,
-                    b->d_ixq, b->d_seg, b->d_frm, b->d_slots, b->d_dur, b->d_order};
+                    b->d_ixq, b->d_seg, b->d_frm, b->d_slots, b->d_dur, b->d_order,
+                    b->d_ixq2, b->d_seg2, b->d_frm2, b->d_slots2, b->d_sgn3, b->d_lens};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 2; i++) {
         if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]);
@@ -156,7 +168,8 @@ extern "C" void hx_batch_destroy(hx_batch *b)
     if (b->s_host) hipStreamDestroy(b->s_host);
     if (b->s_front) hipStreamDestroy(b->s_front);
     if (b->s_alloc) hipStreamDestroy(b->s_alloc);
-    hipEvent_t evs[] = {b->ev_in, b->ev_front[0], b->ev_front[1], b->ev_alloc[0], b->ev_alloc[1]};
+    if (b->s_pack) hipStreamDestroy(b->s_pack);
+    hipEvent_t evs[] = {b->ev_in, b->ev_front[0], b->ev_front[1], b->ev_alloc[0], b->ev_alloc[1], b->ev_k6[0], b->ev_k6[1], b->ev_sgn[0], b->ev_sgn[1], b->ev_sgn[2]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (auto &pr : b->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete b;
@@ -233,6 +246,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
     if (const char *e = getenv("HMP3AMD_LPT")) b->lpt = atoi(e);
+    ALLOC(b->d_lens, sizeof(int) * 4 * S);
     ALLOC(b->d_dur, sizeof(unsigned) * S);
     ALLOC(b->d_order, sizeof(int) * S);
     HIPCHKN(hipMemset(b->d_dur, 0, sizeof(unsigned) * S));
@@ -283,6 +297,7 @@ static int stream_state_copy(hx_batch *b, int i, void *host, bool save)
 {
     if (!b || i < 0 || i >= b->S || !host) { set_err("bad arguments"); return -1; }
     HIPCHK(hipSetDevice(b->device));
+    if (b->s_pack) flush_pack(b, -1);
     HIPCHK(hipDeviceSynchronize());
     HxStateHeader hd = {HX_STATE_MAGIC, HX_STATE_VERSION, (unsigned) sizeof(HxStream), 0, cfg_fingerprint(b->params[b->cls_of[i]])};
     if (save) memcpy(host, &hd, sizeof(hd));
@@ -318,6 +333,7 @@ extern "C" int hx_batch_reset_stream(hx_batch *b, int i)
 {
     if (!b || i < 0 || i >= b->S) { set_err("stream index out of range"); return -1; }
     HIPCHK(hipSetDevice(b->device));
+    if (b->s_pack) flush_pack(b, -1);
     HIPCHK(hipDeviceSynchronize());
     HxStream *st = new HxStream;
     hx_stream_reset(&b->params[b->cls_of[i]], b->cls_of[i], st);
@@ -372,11 +388,19 @@ static int pipe_init(hx_batch *b)
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = least urgent, hi = most urgent
     HIPCHK(hipStreamCreateWithPriority(&b->s_front, hipStreamNonBlocking, lo));
     HIPCHK(hipStreamCreateWithPriority(&b->s_alloc, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&b->s_pack, hipStreamNonBlocking, lo));
     HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&b->ev_alloc[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_k6[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < 3; i++) HIPCHK(hipEventCreateWithFlags(&b->ev_sgn[i], hipEventDisableTiming));
+    HIPCHK(hipMalloc((void **) &b->d_ixq2, sizeof(short) * S * NG * 1152));
+    HIPCHK(hipMalloc((void **) &b->d_seg2, sizeof(HxSegOut) * S * NG * 2));
+    HIPCHK(hipMalloc((void **) &b->d_frm2, sizeof(HxFrameOut) * S * NG));
+    HIPCHK(hipMalloc((void **) &b->d_slots2, sizeof(HxSlot) * S * (NG + HX_SLOTS_EXTRA)));
+    HIPCHK(hipMalloc((void **) &b->d_sgn3, S * NG * 1152));
     HIPCHK(hipMalloc((void **) &b->d_xr2, sizeof(float) * S * NG * 1152));
     HIPCHK(hipMalloc((void **) &b->d_etab2, sizeof(float) * S * NG * 128));
     HIPCHK(hipMalloc((void **) &b->d_thr2, sizeof(float) * S * NG * 128));
@@ -402,6 +426,44 @@ static int check_call(const hx_batch *b, const void *pcm, int nframes, const voi
     return 0;
 }
 
+// the packing kernels of one call on stream qp (see encode_core)
+static int enqueue_pack(hx_batch *b, unsigned char *d_out, long long out_stride, int *d_out_bytes, int nframes, int set, int sset, hipStream_t qp)
+{
+    const int S = b->S, NG = 2 * nframes;
+    unsigned char *const x_sgn = sset == 2 ? b->d_sgn3 : (sset ? b->d_sgn2 : b->d_sgn);
+    short *const x_ixq = set ? b->d_ixq2 : b->d_ixq;
+    HxSegOut *const x_seg = set ? b->d_seg2 : b->d_seg;
+    HxFrameOut *const x_frm = set ? b->d_frm2 : b->d_frm;
+    HxSlot *const x_slots = set ? b->d_slots2 : b->d_slots;
+    int *const x_prelen = b->d_lens + (2 * set) * (long long) b->S, *const x_carrylen = b->d_lens + (2 * set + 1) * (long long) b->S;
+    const int fps = (b->lsf ? 2 : 1) * nframes;
+    const long long total = (long long) S * fps;
+    LAUNCH(k_pack_pre, dim3(S), dim3(64), qp, (const HxStream *) b->d_st, d_out, out_stride, (const int *) x_prelen);
+    LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
+           (const short *) x_ixq, (const unsigned char *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
+           d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total);
+    LAUNCH(k_pack_carry, dim3(S), dim3(64), qp, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes, (const int *) x_carrylen);
+    return 0;
+}
+
+// the deferred packing of the latest submit: out now, on the packing stream; gate_base >= 0: behind a gate on the allocator launch
+// that was just enqueued (the one after the job's own)
+static int flush_pack(hx_batch *b, long long gate_base)
+{
+    hx_batch::PackJob &j = b->pack_job;
+    if (!j.pending) return 0;
+    j.pending = false;
+    HIPCHK(hipStreamWaitEvent(b->s_pack, b->ev_k6[j.set], 0));
+    if (gate_base >= 0 && b->gate_percent > 0) {
+        const long long fill = b->S < b->resident ? b->S : b->resident;
+        LAUNCH(k_gate, dim3(1), dim3(64), b->s_pack, (const unsigned *) (b->d_done + 2), (unsigned) gate_base, (unsigned) (fill * b->gate_percent / 100), b->d_done + 1);
+    }
+    if (enqueue_pack(b, j.d_out, j.out_stride, j.d_out_bytes, j.nframes, j.set, j.sset, b->s_pack) != 0) return -1;
+    HIPCHK(hipEventRecord(b->ev_alloc[j.set], b->s_pack));
+    HIPCHK(hipEventRecord(b->ev_sgn[j.sset], b->s_pack));
+    return 0;
+}
+
 // one pass of the pipeline over the batch; the input is int16 (d_pcm) or fp32 at int16 scale (d_pcm32).
 // pipelined = 0: every kernel on the caller's stream.  pipelined = 1 (hx_batch_submit_*): front end
 // and k_alloc on the batch's own two streams, ordered by events (see hx_batch).
@@ -414,10 +476,12 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     int set = 0;
     if (pipelined) {
         if (pipe_init(b) != 0) return -1;
+        if (pipelined == 2 && flush_pack(b, -1) != 0) return -1;    // (a host-buffer submit behind device-buffer ones)
         set = (int) (b->nsubmit & 1);
         HIPCHK(hipEventRecord(b->ev_in, q));                        // the caller's PCM is ready from here on
         HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_in, 0));
-        if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_alloc[set], 0));     // k_alloc of submit n-2 is done with this set
+        if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_k6[set], 0));        // k_alloc of submit n-2 is done with this set
+        if (b->nsubmit >= 3) HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_sgn[b->nsubmit % 3], 0));     // ... and the packing of submit n-3 with this set of signs
         q = b->s_front; qa = b->s_alloc;
         if (b->alloc_launches > 0 && b->gate_percent > 0) {        // start in the previous allocator kernel's tail, not at its start
             const unsigned base = (unsigned) ((unsigned long long) (b->alloc_launches - 1) * (unsigned long long) b->S);   // wraps with the counter
@@ -426,6 +490,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
             LAUNCH(k_gate, dim3(1), dim3(64), q, (const unsigned *) (b->d_done + 2), base, need, b->d_done + 1);
         }
     } else if (b->inflight) {                                       // a plain call behind submits: order it after them
+        if (flush_pack(b, -1) != 0) return -1;
         const int last = (int) ((b->nsubmit - 1) & 1);
         HIPCHK(hipStreamWaitEvent(q, b->ev_front[last], 0));
         HIPCHK(hipStreamWaitEvent(q, b->ev_alloc[last], 0));
@@ -435,7 +500,15 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     int *const x_msbase = set ? b->d_msbase2 : b->d_msbase;
     unsigned char *const x_bt = set ? b->d_bt2 : b->d_bt, *const x_btprev = set ? b->d_btprev2 : b->d_btprev;
     float *const x_x34 = set ? b->d_x342 : b->d_x34, *const x_thrprev = set ? b->d_thrprev2 : b->d_thrprev;
-    unsigned char *const x_sgn = set ? b->d_sgn2 : b->d_sgn, *const x_msflag = set ? b->d_msflag2 : b->d_msflag;
+    // (the signs are also read by the packing, which may still be busy with submit n-2 when the front end of submit n
+    // writes them: three sets in rotation)
+    const int sset = pipelined ? (int) (b->nsubmit % 3) : 0;
+    unsigned char *const x_sgn = sset == 2 ? b->d_sgn3 : (sset ? b->d_sgn2 : b->d_sgn), *const x_msflag = set ? b->d_msflag2 : b->d_msflag;
+    short *const x_ixq = set ? b->d_ixq2 : b->d_ixq;
+    HxSegOut *const x_seg = set ? b->d_seg2 : b->d_seg;
+    HxFrameOut *const x_frm = set ? b->d_frm2 : b->d_frm;
+    HxSlot *const x_slots = set ? b->d_slots2 : b->d_slots;
+    int *const x_prelen = b->d_lens + (2 * set) * (long long) b->S, *const x_carrylen = b->d_lens + (2 * set + 1) * (long long) b->S;
     HxBandPrep *const x_band = set ? b->d_band2 : b->d_band;
     int *const x_msdec = set ? b->d_msdec2 : b->d_msdec;
     const int S = b->S, NG = 2 * nframes;
@@ -466,6 +539,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     if (pipelined) {
         HIPCHK(hipEventRecord(b->ev_front[set], q));
         HIPCHK(hipStreamWaitEvent(qa, b->ev_front[set], 0));
+        if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(qa, b->ev_alloc[set], 0));     // the packing of submit n-2 is done with the lines / records of this set
     }
     AllocArgs a;
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = x_xr; a.etab = x_etab; a.thr = x_thr;
@@ -480,7 +554,8 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         a.order = b->d_order;
     }
     a.x34 = x_x34; a.sgn = x_sgn; a.band = x_band; a.msflag = x_msflag; a.msdec = x_msdec; a.thrprev = x_thrprev;
-    a.ixq = b->d_ixq; a.sgn_w = x_sgn; a.seg = b->d_seg; a.frm = b->d_frm; a.slots = b->d_slots;
+    a.ixq = x_ixq; a.sgn_w = x_sgn; a.seg = x_seg; a.frm = x_frm; a.slots = x_slots;
+    a.pre_len = x_prelen; a.carry_len = x_carrylen;
     b->alloc_launches++;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
@@ -491,13 +566,20 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     else LAUNCH(k_alloc, dim3(S), dim3(128), qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
-    {   // every frame of the call packed at once, then the incomplete frames' images into the stream state
-        const int fps = (b->lsf ? 2 : 1) * nframes;
-        const long long total = (long long) S * fps;
-        LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qa, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
-               (const short *) b->d_ixq, (const unsigned char *) x_sgn, (const HxSegOut *) b->d_seg, (const HxFrameOut *) b->d_frm, (const HxSlot *) b->d_slots,
-               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total);
-        LAUNCH(k_pack_carry, dim3(S), dim3(64), qa, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes);
+    // Every frame of the call packed at once, between the pending frames' images coming out of the stream state and the
+    // incomplete ones' going back in.  A plain call (and a host-buffer submit) packs right behind its allocator launch.  A
+    // device-buffer submit leaves its packing for later: it is enqueued on a stream of its own behind the NEXT submit's
+    // allocator launch and a gate on it, and so runs - like that submit's successor's front end - in that launch's tail
+    // instead of between two allocator launches.
+    if (pipelined == 1) {
+        HIPCHK(hipEventRecord(b->ev_k6[set], qa));
+        if (flush_pack(b, (long long) ((unsigned long long) (b->alloc_launches - 1) * (unsigned long long) b->S)) != 0) return -1;   // the previous submit's
+        hx_batch::PackJob &j = b->pack_job;
+        j.pending = true; j.d_out = d_out; j.out_stride = out_stride; j.d_out_bytes = d_out_bytes; j.nframes = nframes; j.set = set; j.sset = sset;
+    } else {
+        if (pipelined) HIPCHK(hipEventRecord(b->ev_k6[set], qa));
+        if (enqueue_pack(b, d_out, out_stride, d_out_bytes, nframes, set, sset, qa) != 0) return -1;
+        if (pipelined) { HIPCHK(hipEventRecord(b->ev_alloc[set], qa)); HIPCHK(hipEventRecord(b->ev_sgn[sset], qa)); }
     }
     while (b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events
         const auto old = b->pending.front();
@@ -509,7 +591,6 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         b->pending.erase(b->pending.begin());
     }
     if (pipelined) {
-        HIPCHK(hipEventRecord(b->ev_alloc[set], qa));
         b->nsubmit++;
         b->inflight = true;
     }
@@ -557,6 +638,7 @@ extern "C" int hx_batch_wait(hx_batch *b, void *stream)
     if (!b) return -1;
     if (!b->inflight) return 0;
     HIPCHK(hipSetDevice(b->device));
+    if (flush_pack(b, -1) != 0) return -1;
     const int last = (int) ((b->nsubmit - 1) & 1);
     HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_front[last], 0));
     HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_alloc[last], 0));
@@ -593,6 +675,7 @@ static int submit_host(hx_batch *b, const void *pcm, int is_f32, int nframes, un
         }
     }
     if (pbytes > b->hs_pcm_cap || obytes > b->hs_out_cap) {     // (re)size the staging: drain first
+        if (b->s_pack) flush_pack(b, -1);
         HIPCHK(hipDeviceSynchronize());
         for (int i = 0; i < 2; i++) {
             if (pbytes > b->hs_pcm_cap) { if (b->hs_pcm[i]) hipFree(b->hs_pcm[i]); HIPCHK(hipMalloc(&b->hs_pcm[i], (size_t) pbytes)); }
@@ -611,7 +694,7 @@ static int submit_host(hx_batch *b, const void *pcm, int is_f32, int nframes, un
     HIPCHK(hipStreamWaitEvent(b->s_host, b->ev_h2d[k], 0));
     const int set = (int) (b->nsubmit & 1);
     int r = encode_core(b, is_f32 ? nullptr : (const int16_t *) b->hs_pcm[k], is_f32 ? (const float *) b->hs_pcm[k] : nullptr, nframes,
-                        b->hs_out[k], out_stride, b->hs_nb[k], b->s_host, 1);
+                        b->hs_out[k], out_stride, b->hs_nb[k], b->s_host, 2);
     if (r) return r;
     HIPCHK(hipEventRecord(b->ev_hfront[k], b->s_front));
     HIPCHK(hipStreamWaitEvent(b->s_d2h, b->ev_alloc[set], 0));
@@ -670,6 +753,7 @@ static int encode_host(hx_batch *b, const void *pcm, int is_f32, int nframes, un
     int r = encode_core(b, is_f32 ? nullptr : (const int16_t *) b->d_pcm, is_f32 ? (const float *) b->d_pcm : nullptr, nframes,
                         b->d_out, out_stride, b->d_outbytes, nullptr);
     if (r) return r;
+    if (b->s_pack) flush_pack(b, -1);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_bytes, b->d_outbytes, sizeof(int) * b->S, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out, b->d_out, obytes, hipMemcpyDeviceToHost));
@@ -723,6 +807,7 @@ extern "C" int hx_batch_status(hx_batch *b)
     int v = -1, gate[2] = {0, 0};
     if (!b) return -1;
     hipSetDevice(b->device);
+    if (b->s_pack) flush_pack(b, -1);
     hipDeviceSynchronize();
     if (hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (hipMemcpy(gate, b->d_done, sizeof(gate), hipMemcpyDeviceToHost) == hipSuccess && gate[1] > 0) v |= 8;
@@ -735,6 +820,7 @@ extern "C" int hx_batch_gate_timeouts(hx_batch *b)
     int gate[2] = {0, 0};
     if (!b) return -1;
     hipSetDevice(b->device);
+    if (b->s_pack) flush_pack(b, -1);
     hipDeviceSynchronize();
     if (hipMemcpy(gate, b->d_done, sizeof(gate), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return gate[1];
@@ -745,6 +831,7 @@ extern "C" HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int i)
     HX_INT_PAIR r = {0, 0};
     if (!b || i < 0 || i >= b->S) return r;
     hipSetDevice(b->device);
+    if (b->s_pack) flush_pack(b, -1);
     hipDeviceSynchronize();
     unsigned v[2];
     hipMemcpy(&v[0], (char *) (b->d_st + i) + offsetof(HxStream, tot_frames_out), 4, hipMemcpyDeviceToHost);
@@ -757,6 +844,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
 {
     if (!b || !name || !dst) return -1;
     hipSetDevice(b->device);
+    if (b->s_pack) flush_pack(b, -1);
     hipDeviceSynchronize();
     const long long S = b->S, NG = b->lastNG;
     const void *src = nullptr;

@@ -215,15 +215,26 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
 }
 
 // Frames whose slot is not full yet travel to the next call in the stream state: their images (headers, side
-// information, the main data written so far) follow the complete frames in `out`.
+// information, the main data written so far) follow the complete frames in `out` (k_pack_carry, after the packing),
+// and are put at the head of the next call's `out` before its packing (k_pack_pre).  The lengths are per call
+// (written by that call's allocator launch), because the next call's allocator may already have run.
 __global__ __launch_bounds__(64) void k_pack_carry(HxStream *__restrict__ st, const unsigned char *__restrict__ out, long long out_stride,
-                                                   const int *__restrict__ out_bytes)
+                                                   const int *__restrict__ out_bytes, const int *__restrict__ carry_len)
 {
     const int s = blockIdx.x;
     HxStream *ss = st + s;
     const unsigned char *src = out + (long long) s * out_stride + out_bytes[s];
-    const int n = ss->main_p1;
+    const int n = carry_len[s];
     for (int i = threadIdx.x; i < n; i += 64) ss->main_buf[i] = src[i];
+}
+__global__ __launch_bounds__(64) void k_pack_pre(const HxStream *__restrict__ st, unsigned char *__restrict__ out, long long out_stride,
+                                                 const int *__restrict__ pre_len)
+{
+    const int s = blockIdx.x;
+    const HxStream *ss = st + s;
+    unsigned char *dst = out + (long long) s * out_stride;
+    const int n = pre_len[s];
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = ss->main_buf[i];
 }
 
 // Workgroup order of the next allocator launch: streams by this launch's duration, longest first (a counting sort on

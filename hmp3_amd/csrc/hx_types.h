@@ -199,6 +199,7 @@ struct AllocArgs {
     long long packet_stride;
     int *packet_bytes;          // [S][F]
     int *frame_stats;           // optional [S][F][2]: frames / bytes emitted by the stream after each input frame
+    int *pre_len, *carry_len;   // [S] bytes of pending frames' images at the call's start (k_pack_pre copies them in) / at its end (k_pack_carry saves them)
     const int *order;           // workgroup -> stream (longest-running first, from the previous call's durations), or null = identity
     unsigned *dur;              // [S] this call's duration of each stream's workgroup, 100 MHz ticks
     int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter)
