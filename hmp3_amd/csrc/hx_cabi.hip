@@ -540,6 +540,19 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         HIPCHK(hipEventRecord(b->ev_front[set], q));
         HIPCHK(hipStreamWaitEvent(qa, b->ev_front[set], 0));
         if (b->nsubmit >= 2) HIPCHK(hipStreamWaitEvent(qa, b->ev_alloc[set], 0));     // the packing of submit n-2 is done with the lines / records of this set
+        // A caller that hands consecutive submits the same output buffers gets them one after the other: the previous
+        // submit's packing (which writes and reads its `out`) then has to be through before this allocator launch
+        // starts putting headers into it.  Alternate two sets of output buffers to have them overlap.
+        const hx_batch::PackJob &j = b->pack_job;
+        if (j.pending) {
+            const unsigned char *o0 = j.d_out, *o1 = j.d_out + (long long) b->S * j.out_stride, *n0 = d_out, *n1 = d_out + (long long) b->S * out_stride;
+            const char *b0 = (const char *) j.d_out_bytes, *b1 = b0 + sizeof(int) * (size_t) b->S, *m0 = (const char *) d_out_bytes, *m1 = m0 + sizeof(int) * (size_t) b->S;
+            if ((o0 < n1 && n0 < o1) || (b0 < m1 && m0 < b1)) {
+                const int js = j.set;
+                if (flush_pack(b, -1) != 0) return -1;
+                HIPCHK(hipStreamWaitEvent(qa, b->ev_alloc[js], 0));
+            }
+        }
     }
     AllocArgs a;
     a.st = b->d_st; a.prm = b->d_prm; a.gt = b->d_gt; a.xr = x_xr; a.etab = x_etab; a.thr = x_thr;

@@ -133,8 +133,10 @@ int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nframes, unsigne
    call on the CPU).  A submit is asynchronous like the plain call, but its outputs are ordered on
    `stream` only by a later hx_batch_wait (or by the next plain / host-buffer call on the batch); the
    PCM must be ready on `stream` at the submit and stay unchanged until hx_batch_wait.  Consecutive
-   submits overlap: the front-end kernels of call n+1 run on the SIMDs that the allocator kernel of
-   call n leaves idle while its slowest streams finish. */
+   submits overlap: the front-end kernels of call n+1 and the bit packing of call n-1 run on the SIMDs
+   that the allocator kernel of call n leaves idle while its slowest streams finish.  Hand consecutive
+   submits different d_out / d_out_bytes (two sets in turn): with overlapping ones the result is the
+   same, but the allocator launch waits for the previous call's packing. */
 int hx_batch_submit_s16_device(hx_batch *b, const int16_t *d_pcm, int nframes, unsigned char *d_out,
                                long long out_stride, int *d_out_bytes, void *stream);
 int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int nframes, unsigned char *d_out,

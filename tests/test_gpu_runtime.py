@@ -167,3 +167,43 @@ def test_longest_first_workgroup_order_changes_nothing_in_the_output(monkeypatch
         want = b"".join(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F * calls))
         assert got[s] == want, "stream %d" % s
     b.close()
+
+
+@pytest.mark.gpu
+def test_submits_into_one_output_buffer_are_run_one_after_the_other():
+    """The packing of a device-buffer submit is deferred behind the next submit's allocator launch; a caller that hands
+    every submit the same output buffers must still get the last call's bytes right (the library then orders the
+    packing in front of the next allocator launch), and a stream checkpoint taken with a packing job pending is complete"""
+    import numpy as np
+    import torch
+    from hmp3_amd import api, synth
+    S, F, calls = 40, 10, 5
+    kw = dict(vbr_mnr=70)
+    pcm = np.stack([synth.stream_pcm(8800 + i, F * calls, rho=[0.7, 0.0, 1.0, 0.3][i % 4], bursts=True) for i in range(S)])
+    b0 = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    want = [b0.encode_host(np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])) for c in range(calls)]
+    b0.close()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    d_pcm = [torch.from_numpy(np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])).to(dev) for c in range(calls)]
+    b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    stride = b.out_stride(F)
+    d_out = torch.zeros((S, stride), dtype=torch.uint8, device=dev)
+    d_nb = torch.zeros((S,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for c in range(calls - 1):
+        b.submit_device(d_pcm[c].data_ptr(), F, d_out.data_ptr(), stride, d_nb.data_ptr(), st)
+    blob = b.get_stream_state(3)            # with the fourth call's packing still pending
+    b.submit_device(d_pcm[calls - 1].data_ptr(), F, d_out.data_ptr(), stride, d_nb.data_ptr(), st)
+    b.wait(st)
+    torch.cuda.synchronize()
+    assert b.status() == 0
+    o, n = d_out.cpu().numpy(), d_nb.cpu().numpy()
+    for s in range(S):
+        assert o[s, :n[s]].tobytes() == want[calls - 1][s], "stream %d" % s
+    # the checkpoint continues in another batch with the last call's bytes
+    b2 = api.Batch(api.default_control(**kw), nstreams=1, max_frames=F)
+    b2.set_stream_state(0, blob)
+    got = b2.encode_host(np.ascontiguousarray(pcm[3:4, (calls - 1) * F * 1152:calls * F * 1152]))
+    assert got[0] == want[calls - 1][3]
+    b.close(); b2.close()
