@@ -249,8 +249,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; the first one's front end and the last one's packing have nothing to hide behind, so few steps understate the steady rate")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[n-1]")
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: the config's)")
