@@ -207,3 +207,46 @@ def test_submits_into_one_output_buffer_are_run_one_after_the_other():
     got = b2.encode_host(np.ascontiguousarray(pcm[3:4, (calls - 1) * F * 1152:calls * F * 1152]))
     assert got[0] == want[calls - 1][3]
     b.close(); b2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,nch", [(dict(bitrate=32, samprate=22050), 2), (dict(bitrate=64, mode=3), 1), (dict(bitrate=64, mode=2), 2),
+                                    (dict(bitrate=8, samprate=16000), 2), (dict(vbr_mnr=40, samprate=24000), 2), (dict(vbr_mnr=90, hf_flag=3, samprate=48000), 2)],
+                         ids=["lsf_cbr64", "mono_cbr64", "dual_channel", "lsf_intensity", "lsf_vbr", "vbr_hf2_48k"])
+def test_submit_path_for_every_stream_type(kw, nch):
+    """device-buffer submits back to back (front end, allocator launch and packing of neighbouring calls overlapped) against
+    plain calls: MPEG-2 frame-per-granule streams, mono, both allocators, the HF modes"""
+    import numpy as np
+    import torch
+    from hmp3_amd import api, synth
+    S, F, calls = 48, 8, 5
+    sr = kw.get("samprate", 44100)
+    pcm = np.stack([synth.stream_pcm(9900 + i, F * calls, sr=sr, rho=[0.7, 0.0, 1.0, 0.3][i % 4], bursts=True) for i in range(S)])
+    if nch == 1:
+        pcm = np.ascontiguousarray(pcm[:, :, 0])
+    cut = lambda c: np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])
+    b0 = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    want = [b0.encode_host(cut(c)) for c in range(calls)]
+    assert b0.status() == 0
+    b0.close()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    d_pcm = [torch.from_numpy(cut(c)).to(dev) for c in range(calls)]
+    b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    stride = b.out_stride(F)
+    d_out = [torch.zeros((S, stride), dtype=torch.uint8, device=dev) for _ in range(calls)]
+    d_nb = [torch.zeros((S,), dtype=torch.int32, device=dev) for _ in range(calls)]
+    torch.cuda.synchronize()
+    for c in range(calls):      # back to back: the packing of call c goes out behind the allocator launch of call c + 1
+        b.submit_device(d_pcm[c].data_ptr(), F, d_out[c].data_ptr(), stride, d_nb[c].data_ptr(), st)
+    b.wait(st)
+    torch.cuda.synchronize()
+    got = []
+    for c in range(calls):
+        o, n = d_out[c].cpu().numpy(), d_nb[c].cpu().numpy()
+        got.append([o[s, :n[s]].tobytes() for s in range(S)])
+    assert b.status() == 0
+    for c in range(calls):
+        for s in range(S):
+            assert got[c][s] == want[c][s], "call %d stream %d" % (c, s)
+    b.close()
