@@ -19,6 +19,9 @@ struct alignas(16) PackLds {
     unsigned char huff_len[1408];
     int tabpk[32];                      // per Huffman table: code offset | row stride << 12 | linbits << 20
     unsigned char quada_code[16], quada_len[16];
+    unsigned short sf[4][40];           // the frame's scalefactor fields (kept for unmasked_writer_fixup)
+    int seghdr[4][8];                   // ... and its segment records
+    int negflag;                        // some scalefactor of the frame is negative
 };
 
 // OR an n-bit field (n <= 32) at absolute bit position pos
@@ -125,6 +128,58 @@ __device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsi
     return pos;
 }
 
+// The reference's bit writer does `bitbuf = (bitbuf << n) | x` without masking x (l3pack.c bitput), and the
+// first-generation allocator can hand it a negative scalefactor: its upper bits then land on the bits written before
+// it that have not left the 32-bit buffer yet.  Which those are depends on the writer's flush state, i.e. on the size of
+// every single put since the frame's main data began (a put that does not fit flushes whole bytes until at least 24
+// bits are free).  Rare (a few frames in a thousand dual-channel / intensity streams), so one lane replays the frame's
+// sequence of put sizes - scalefactor fields, then per pair code / linbits / sign / linbits / sign, then the quads -
+// and ORs the stray bits in where a negative field turns up.  The fields' own low bits are already in place.
+__device__ __noinline__ void unmasked_writer_fixup(PackLds &L, int nseg)
+{
+    int P = 0;          // bits in the writer's buffer
+    auto put = [&](int n) { if (32 - P < n) P = ((P - 1) & 7) + 1; P += n; };
+    for (int w = 0; w < nseg; w++) {
+        const int *h = L.seghdr[w];
+        if (!h[7]) continue;                    // not this stream's segment (mono) 
+        int pos = h[0];
+        for (int j = 0; j < 40; j++) {
+            const int fld = L.sf[w][j];
+            if (!fld) continue;
+            const int n = (fld >> 8) & 15;
+            if (32 - P < n) P = ((P - 1) & 7) + 1;
+            if (fld & 0x8000) {
+                const int x = (int) (signed char) (fld & 255);
+                const unsigned stray = (unsigned) (x >> n) & (P >= 32 ? 0xFFFFFFFFu : ((1u << P) - 1u));
+                if (P > 0) put_bits(L, pos - P, stray, P);
+            }
+            P += n; pos += n;
+        }
+        if (!h[5]) continue;                    // no Huffman data
+        const unsigned r01 = (unsigned) h[2], r2q = (unsigned) h[3], tabs = (unsigned) h[4];
+        const int n0 = r01 & 0xFFFF, n1 = r01 >> 16, n2 = r2q & 0xFFFF, npairs = n0 + n1 + n2;
+        const unsigned short *ix = L.ix[w];
+        for (int pi = 0; pi < npairs; pi++) {
+            const int pk = L.tabpk[(pi < n0) ? (tabs & 31) : (pi < n0 + n1 ? ((tabs >> 8) & 31) : ((tabs >> 16) & 31))];
+            const int dim = (pk >> 12) & 0xFF, lin = pk >> 20;
+            if (dim == 0) continue;
+            const int x = ix[2 * pi], y = ix[2 * pi + 1];
+            put(L.huff_len[(pk & 0xFFF) + min(x, 15) * dim + min(y, 15)]);
+            if (x >= 15 && lin) put(lin);
+            if (x) put(1);
+            if (y >= 15 && lin) put(lin);
+            if (y) put(1);
+        }
+        const int nq = (int) (r2q >> 16), c1sel = (int) (tabs >> 24);
+        for (int q = 0; q < nq; q++) {
+            const unsigned short *v = ix + 2 * npairs + 4 * q;
+            const int code = (v[0] << 3) + (v[1] << 2) + (v[2] << 1) + v[3];
+            put(c1sel == 1 ? 4 : L.quada_len[code & 15]);
+            for (int k = 0; k < 4; k++) if (v[k]) put(1);
+        }
+    }
+}
+
 // frames_per_stream = frames a stream produces per call (nframes, or 2 nframes at the MPEG-2 rates where every
 // granule is a frame); lsf selects that layout.  The grid is sized to fill the chip once; a workgroup stages the
 // code tables once and then takes every gridDim.x-th frame.
@@ -146,6 +201,7 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
     for (long long fr = blockIdx.x; fr < nframes_total; fr += gridDim.x) {
         const int s = (int) (fr / frames_per_stream), f = (int) (fr % frames_per_stream);
         for (int i = tid; i < 640; i += 256) L.bitw[i] = 0;
+        if (tid == 0) L.negflag = 0;
         const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
         const int nchan = p->nchan, hdr = 4 + p->side_bytes;
         // wave w <-> segment (granule, channel)
@@ -173,14 +229,17 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
             if (lane < 36) ds[lane] = a2;
         }
         const int not_null = h1.y;
+        if (lane < 40) L.sf[w][lane] = (unsigned short) fld;
+        if (lane == 0) { int *h = L.seghdr[w]; h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[7] = mine ? 1 : 0; }
         __syncthreads();
         if (mine) {
             int pos = h0.x;                                 // start_bit
-            {   // scalefactor fields in transmission order
-                const int len = fld >> 8;
+            {   // scalefactor fields in transmission order: value | length << 8 | negative << 15
+                const int len = (fld >> 8) & 15;
                 const int incl = hx_wave_scan(len);
-                if (len) put_bits(L, pos + incl - len, (unsigned) (fld & 255), len);
+                if (len) put_bits(L, pos + incl - len, (unsigned) (fld & 255) & ((1u << len) - 1u), len);
                 pos += __builtin_amdgcn_readlane(incl, 63);
+                if (__any(fld & 0x8000) && lane == 0) L.negflag = 1;
             }
             if (not_null) {
                 const int hb = pos;
@@ -189,6 +248,10 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
             }
         }
         __syncthreads();
+        if (L.negflag) {        // (workgroup-uniform)
+            if (tid == 0) unmasked_writer_fixup(L, lsf ? 2 : 4);
+            __syncthreads();
+        }
         // the frame's main data (zero stuffing up to byte_min included) into the pending slots, oldest first; the first
         // four slots' offsets and sizes are in registers (requested with the segment data), the walk rarely goes further
         const HxSlot *sl = slots + (long long) s * (frames_per_stream + HX_SLOTS_EXTRA);

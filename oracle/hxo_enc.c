@@ -596,8 +596,10 @@ static int encode_joint_a1(hxo_encoder *e, hxo_bitw *w)
         psy_long_all(e, igr);
         hxo_bitallo1(e, s->xr[igr], s->sig_mask, 0, 2, ba_min, TargetBits, ba_max, s->sf[igr], s->gr[igr], s->ix, s->signx, ms);
         if (e->dbg) {
+            int i;
             memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
             memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+            for (ch = 0; ch < 2; ch++) for (i = 0; i < 22; i++) e->dbg->sf[igr][ch][i] = s->sf[igr][ch].l[i];
         }
         for (ch = 0; ch < 2; ch++) {
             hxo_gr *g = &s->gr[igr][ch];
@@ -652,8 +654,10 @@ static int encode_single_a1(hxo_encoder *e, hxo_bitw *w)
             g->part2_3_length = bits;
         }
         if (e->dbg) {
+            int i;
             memcpy(e->dbg->ix[igr], s->ix, sizeof(s->ix));
             memcpy(e->dbg->signx[igr], s->signx, sizeof(s->signx));
+            for (ch = 0; ch < 2; ch++) for (i = 0; i < 22; i++) e->dbg->sf[igr][ch][i] = s->sf[igr][ch].l[i];
         }
     }
     s->scfsi[0] = s->scfsi[1] = 0;

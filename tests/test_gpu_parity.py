@@ -124,6 +124,26 @@ def test_loud_near_mono_material_takes_the_double_table_path(kw):
     b.close()
 
 
+NEG_SF_CASES = [   # found by tools/fuzz_parity.py: quiet dual-channel VBR material
+    (dict(samprate=48000, mode=2, vbr_mnr=131), 109814, 0.0, 12, False),
+    (dict(samprate=48000, mode=2, vbr_mnr=36, hf_flag=3, short_block_threshold=2000, filter_select=1), 370635, 0.7, 12, True),
+]
+
+
+@pytest.mark.parametrize("kw,seed,rho,F,bursts", NEG_SF_CASES, ids=["dual_vbr131", "dual_vbr36_hf"])
+def test_negative_scalefactors_go_through_the_unmasked_bit_writer(kw, seed, rho, F, bursts):
+    """The first-generation allocator leaves an empty band's scalefactor at 0 - pretab when pre-emphasis is on (reference
+    bitallo1.cpp:547-586); the reference's bit writer ORs the negative value into its buffer unmasked, which sets bits
+    written just before it.  k_pack replays the writer's flush state to put the same stray bits in (hx_pack.hip)."""
+    pcm = synth.stream_pcm(seed, F, sr=kw["samprate"], rho=rho, bursts=bursts)
+    pcm = (pcm.astype(np.float64) * 0.02).astype(np.int16)[None]
+    b = api().Batch(api().default_control(**kw), nstreams=1, max_frames=F)
+    got = b.encode_host(pcm)[0]
+    assert b.status() == 0
+    assert got == oracle_bytes(kw, pcm[0], F)
+    b.close()
+
+
 @pytest.mark.parametrize("kw", [dict(bitrate=64), dict(vbr_mnr=60)], ids=["cbr128", "vbr60"])
 def test_packet_variant_matches_oracle(kw):
     """CMp3Enc::L3_audio_encode_Packet: bitstream plus the self-contained packet of every frame"""

@@ -257,3 +257,25 @@ def test_first_generation_allocator_stress_signals():
             a = O.encode_stream(O.RefEncoder(O.default_control(**kw)), pcm)
             b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
             assert a == b, kw
+
+
+@pytest.mark.parametrize("kw,seed,rho,F,bursts", [
+    (dict(samprate=48000, mode=2, vbr_mnr=131), 109814, 0.0, 12, False),
+    (dict(samprate=48000, mode=2, vbr_mnr=36, hf_flag=3, short_block_threshold=2000, filter_select=1), 370635, 0.7, 12, True)],
+    ids=["dual_vbr131", "dual_vbr36_hf"])
+def test_negative_scalefactor_frames_byte_identical(kw, seed, rho, F, bursts):
+    """quiet dual-channel material on which the first-generation allocator writes negative scalefactors through the
+    reference's unmasked bit writer (cases found by tools/fuzz_parity.py)"""
+    pcm = synth.stream_pcm(seed, F, sr=kw["samprate"], rho=rho, bursts=bursts)
+    pcm = (pcm.astype(np.float64) * 0.02).astype(np.int16)
+    a = O.encode_stream(O.RefEncoder(O.default_control(**kw)), pcm)
+    b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+    assert len(a) > 0 and a == b
+
+
+def test_random_controls_byte_identical():
+    """a slice of tools/fuzz_oracle_vs_ref.py: random controls x random signals"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_vs_ref.py"), "40", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-800:]

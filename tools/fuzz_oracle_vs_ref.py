@@ -1,0 +1,43 @@
+"""Randomised pin of the oracle against the real reference (oracle/_ref; this container only): random controls x random
+signals, byte for byte.  python tools/fuzz_oracle_vs_ref.py [n_cases] [seed]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hmp3_amd import synth
+from oracle import oracle as O
+assert O.ref() is not None, "make -C oracle ref first"
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
+RATES = [16000, 22050, 24000, 32000, 44100, 48000]
+bad = done = tried = 0
+while done < n_cases and tried < 30 * n_cases:
+    tried += 1
+    sr = int(rs.choice(RATES))
+    kw = dict(samprate=sr, mode=int(rs.choice([0, 0, 1, 1, 1, 2, 3])))
+    if rs.rand() < 0.5: kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
+    else: kw["vbr_mnr"] = int(rs.randint(0, 151))
+    if rs.rand() < 0.3: kw["hf_flag"] = int(rs.choice([1, 3]))
+    if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000, 21000]))
+    if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
+    if rs.rand() < 0.15: kw["filter_select"] = 1
+    if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
+    ok_o = O.OracleEncoder(O.default_control(**kw)).ok()
+    r = O.RefEncoder(O.default_control(**kw))
+    ok_r = r.bytes_in > 0
+    if ok_o != ok_r:
+        print("INIT MISMATCH", kw, "oracle", ok_o, "reference", ok_r); bad += 1; done += 1
+        continue
+    if not ok_r:
+        continue
+    F = int(rs.choice([10, 20, 40]))
+    pcm = synth.stream_pcm(int(rs.randint(0, 1 << 20)), F, sr=sr, rho=float(rs.choice([0.0, 0.3, 0.7, 1.0])), bursts=bool(rs.rand() < 0.6))
+    pcm = (pcm.astype(np.float64) * float(rs.choice([1.0, 1.0, 0.25, 0.02]))).astype(np.int16)
+    if kw["mode"] == 3:
+        pcm = np.ascontiguousarray(pcm[:, 0])
+    a = O.encode_stream(r, pcm)
+    b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+    if a != b:
+        print("MISMATCH", kw, len(a), len(b)); bad += 1
+    done += 1
+print("oracle vs reference fuzz: %d cases, %d bad" % (done, bad))
+sys.exit(1 if bad else 0)

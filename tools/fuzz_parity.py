@@ -1,0 +1,58 @@
+"""Randomised parity sweep: random encoder controls x random synthetic streams, GPU batch (plain and submit path) against the
+CPU oracle.  python tools/fuzz_parity.py [n_cases] [seed].  Prints every mismatch; exit code 1 if there was one."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hmp3_amd import api, synth
+from oracle import oracle as O
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+RATES = [16000, 22050, 24000, 32000, 44100, 48000]
+bad = 0
+done = 0
+tried = 0
+while done < n_cases and tried < 20 * n_cases:
+    tried += 1
+    sr = int(rs.choice(RATES))
+    kw = dict(samprate=sr)
+    mode = int(rs.choice([0, 0, 1, 1, 1, 2, 3]))
+    kw["mode"] = mode
+    if rs.rand() < 0.5:
+        kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
+    else:
+        kw["vbr_mnr"] = int(rs.randint(0, 151))
+    if rs.rand() < 0.3: kw["hf_flag"] = int(rs.choice([1, 3]))
+    if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000, 21000]))
+    if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
+    if rs.rand() < 0.15: kw["filter_select"] = 1
+    if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
+    ec = O.default_control(**kw)
+    if not O.OracleEncoder(ec).ok():
+        continue
+    nch = 1 if mode == 3 else 2
+    S, F = 6, int(rs.choice([7, 12, 20]))
+    seeds = rs.randint(0, 1 << 20, size=S)
+    rhos = rs.choice([0.0, 0.3, 0.7, 1.0], size=S)
+    amp = rs.choice([1.0, 1.0, 0.25, 0.02], size=S)
+    pcm = np.stack([synth.stream_pcm(int(seeds[i]), F, sr=sr, rho=float(rhos[i]), bursts=bool(rs.rand() < 0.6)) for i in range(S)])
+    pcm = (pcm.astype(np.float64) * amp[:, None, None]).astype(np.int16)
+    if nch == 1:
+        pcm = np.ascontiguousarray(pcm[:, :, 0])
+    try:
+        b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    except Exception as e:
+        print("CREATE FAILED", kw, e); bad += 1; done += 1; continue
+    got = b.encode_host(pcm)
+    st = b.status()
+    b.close()
+    for s in range(S):
+        enc = O.OracleEncoder(O.default_control(**kw))
+        want = b"".join(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F))
+        if got[s] != want or st != 0:
+            print("MISMATCH", kw, "stream", s, "seed", int(seeds[s]), "rho", float(rhos[s]), "amp", float(amp[s]), "status", st, len(got[s]), len(want))
+            bad += 1
+            break
+    done += 1
+print("fuzz: %d cases, %d bad" % (done, bad))
+sys.exit(1 if bad else 0)
