@@ -32,6 +32,15 @@ while done < n_cases and tried < 30 * n_cases:
     F = int(rs.choice([10, 20, 40]))
     pcm = synth.stream_pcm(int(rs.randint(0, 1 << 20)), F, sr=sr, rho=float(rs.choice([0.0, 0.3, 0.7, 1.0])), bursts=bool(rs.rand() < 0.6))
     pcm = (pcm.astype(np.float64) * float(rs.choice([1.0, 1.0, 0.25, 0.02]))).astype(np.int16)
+    n = F * 1152
+    kind = int(rs.randint(0, 12))
+    if kind == 0: pcm[:] = 0
+    elif kind == 1: pcm[:] = np.where((np.arange(n) // int(rs.randint(2, 200))) % 2 == 0, 32767, -32768).astype(np.int16)[:, None]
+    elif kind == 2: pcm[:] = rs.randint(-32768, 32768, size=(n, 2)).astype(np.int16)
+    elif kind == 3: pcm[:] = 0; pcm[::int(rs.randint(50, 3000))] = 32767
+    elif kind == 4: pcm[:] = (32000 * np.sin(2 * np.pi * float(rs.uniform(20, sr / 2.1)) * np.arange(n) / sr)).astype(np.int16)[:, None]
+    elif kind == 5: pcm[:] = np.clip(pcm.astype(np.int32) + int(rs.randint(-20000, 20000)), -32768, 32767).astype(np.int16)
+    elif kind == 6: pcm[:, 1] = -pcm[:, 0]
     if kw["mode"] == 3:
         pcm = np.ascontiguousarray(pcm[:, 0])
     a = O.encode_stream(r, pcm)

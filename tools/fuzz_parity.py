@@ -37,13 +37,32 @@ while done < n_cases and tried < 20 * n_cases:
     amp = rs.choice([1.0, 1.0, 0.25, 0.02], size=S)
     pcm = np.stack([synth.stream_pcm(int(seeds[i]), F, sr=sr, rho=float(rhos[i]), bursts=bool(rs.rand() < 0.6)) for i in range(S)])
     pcm = (pcm.astype(np.float64) * amp[:, None, None]).astype(np.int16)
+    # a few extreme signals: silence, full-scale square wave, full-scale noise, impulses, one sine, DC offset
+    n = F * 1152
+    kind = int(rs.randint(0, 12))
+    if kind == 0: pcm[0] = 0
+    elif kind == 1: pcm[0] = np.where((np.arange(n) // int(rs.randint(2, 200))) % 2 == 0, 32767, -32768).astype(np.int16)[:, None]
+    elif kind == 2: pcm[0] = rs.randint(-32768, 32768, size=(n, 2)).astype(np.int16)
+    elif kind == 3: pcm[0] = 0; pcm[0, ::int(rs.randint(50, 3000))] = 32767
+    elif kind == 4: pcm[0] = (32000 * np.sin(2 * np.pi * float(rs.uniform(20, sr / 2.1)) * np.arange(n) / sr)).astype(np.int16)[:, None]
+    elif kind == 5: pcm[0] = np.clip(pcm[0].astype(np.int32) + int(rs.randint(-20000, 20000)), -32768, 32767).astype(np.int16)
+    elif kind == 6: pcm[0, :, 1] = -pcm[0, :, 0]        # anti-phase channels
     if nch == 1:
         pcm = np.ascontiguousarray(pcm[:, :, 0])
     try:
         b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
     except Exception as e:
         print("CREATE FAILED", kw, e); bad += 1; done += 1; continue
-    got = b.encode_host(pcm)
+    b.close()
+    # the same frames in random-sized calls through one batch (state carried from call to call)
+    b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
+    got = [b"" for _ in range(S)]
+    f0 = 0
+    while f0 < F:
+        nf = int(rs.randint(1, F - f0 + 1))
+        out = b.encode_host(np.ascontiguousarray(pcm[:, f0 * 1152:(f0 + nf) * 1152]))
+        for s in range(S): got[s] += out[s]
+        f0 += nf
     st = b.status()
     b.close()
     for s in range(S):
