@@ -171,7 +171,7 @@ struct alignas(16) AllocLds {
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_FETCH };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_FETCH, HCMD_QUANT_COUNT };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \
@@ -1145,6 +1145,29 @@ __device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
     // the channels are counted at the same time: channel 1 by the helper wave
     const bool two = p->nchan == 2;
     if (two) HELPER_POST(HCMD_COUNT_BITS, ncb[1]);
+    int bits = count_bits_ch(L, p, 0, ncb[0]);
+    if (two) { HELPER_JOIN(); bits += L.hs_bits[1]; }
+    SYNC();
+    return bits;
+}
+
+// Quantise and count in one work order (do_quant followed by count_bits when no HF lines are quantised in between):
+// each wave quantises its channel's lines and goes straight on to count them, one hand-over to the helper instead of two.
+// zero21: clear the mid channel's entry of band 21 before counting (M/S granules, reference bitallo3.cpp:640-645).
+__device__ int quant_count_bits(AllocLds &L, const AllocPrm *p, int opt, int zero21, const int *ncb)
+{
+    const int ch = LANE >> 5, i = LANE & 31;
+    if (i < NB) {
+        L.ixmax[ch][i] = (i < p->nsf[ch]) ? 0 : L.ixmax[ch][i];
+        L.gig[ch][i] = L.look_34igain[L.gsf[ch][i] & 127];
+    }
+    SYNC();
+    PROF_CNT(22);
+    const bool two = p->nchan == 2;
+    if (two) HELPER_POST2(HCMD_QUANT_COUNT, opt, ncb[1]);
+    quant_lines(L, p, opt, 0);
+    SYNC();
+    if (zero21) { if (LANE == 0) L.ixmax[0][21] = 0; SYNC(); }
     int bits = count_bits_ch(L, p, 0, ncb[0]);
     if (two) { HELPER_JOIN(); bits += L.hs_bits[1]; }
     SYNC();
