@@ -532,7 +532,7 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
     // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
     LAUNCH(k_msscan, dim3(S), dim3(64), q, b->d_st, b->d_prm, x_msbase, x_bt, x_msflag, x_msdec, x_thr, x_thrprev, NG, b->lsf);
-    LAUNCH(k_prep, dim3((unsigned) (((long long) S * NG + 3) / 4)), dim3(256), q, (const float *) x_xr, (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, x_x34, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
+    LAUNCH(k_prep, dim3((unsigned) (((long long) S * NG + 3) / 4)), dim3(256), q, (const float *) x_xr, (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, b->debug ? x_x34 : (float *) nullptr, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
            x_etab, x_thr, x_thrprev, NG, (long long) S * NG);
     // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
     LAUNCH(k_carry, dim3(S * 2), dim3(256), q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
@@ -876,6 +876,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }
     else if (k == "thr") { src = b->d_thr; n = sizeof(float) * S * NG * 128; }
     else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }
+    else if (k == "dur") { src = b->d_dur; n = sizeof(unsigned) * S; }              // the last allocator launch's per-stream durations, 100 MHz ticks
     else if (k == "big_sweeps") { src = b->d_done + 3; n = sizeof(int); }        // gain-search line passes that took the double x^(4/3) table
     else if (k == "bt") { src = b->d_bt; n = S * NG; }
     else if (k == "eng") { src = b->d_eng; n = sizeof(int) * S * 2 * NG * 9; }

@@ -911,10 +911,10 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
         bp->xsxx[ch][i] = e_lr; bp->x34max[ch][i] = xm; bp->n0[ch][i] = n0; bp->n0ms[ch][i] = n0ms;
         bp->gzero[ch][i] = gz; bp->maskmb[ch][i] = mmb;
     }
-    {   // x^(3/4) and signs to their buffers, straight from the owning lanes.  The magnitudes themselves are not stored:
-        // the allocator's helper wave forms them again from the spectrum it fetches (two operations per line, no
-        // rounding) - cheaper than 2.4 GB of stores and as many loads per launch.  (xmag_dbg: the tests' tap.)
-        float4 *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);
+    {   // The signs to their buffer, straight from the owning lanes.  Magnitudes and x^(3/4) are not stored: the allocator's
+        // helper wave forms them again from the spectrum it fetches, in time it would otherwise spend waiting - cheaper
+        // than 4.8 GB of stores and as many loads per launch.  (xmag_dbg, x34o: the tests' taps.)
+        float4 *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);     // (x34o: the tests' tap; the allocator's helper wave computes x^(3/4) again)
         unsigned *ds = reinterpret_cast<unsigned *>(sgn + unit * 1152);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -925,8 +925,10 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
                     dx[e] = make_float4(a0[k][0], a0[k][1], a0[k][2], a0[k][3]);
                     dx[144 + e] = make_float4(a1[k][0], a1[k][1], a1[k][2], a1[k][3]);
                 }
-                dq[e] = make_float4(q0[k][0], q0[k][1], q0[k][2], q0[k][3]);
-                dq[144 + e] = make_float4(q1[k][0], q1[k][1], q1[k][2], q1[k][3]);
+                if (x34o) {
+                    dq[e] = make_float4(q0[k][0], q0[k][1], q0[k][2], q0[k][3]);
+                    dq[144 + e] = make_float4(q1[k][0], q1[k][1], q1[k][2], q1[k][3]);
+                }
                 ds[e] = s0[k];
                 ds[144 + e] = s1[k];
             }

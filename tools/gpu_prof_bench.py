@@ -1,30 +1,29 @@
-"""Per-stream time distribution of k_alloc on the bench workload (HX_PROFILE build)."""
+"""Per-stream phase profile of k_alloc on the bench's own signal set (1024 distinct streams): where the slowest streams
+spend their time.  Library built with HX_EXTRA=-DHX_PROFILE."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from hmp3_amd import api
 import bench
-S, F = 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+from hmp3_amd import api
+S, F = 1024, int(os.environ.get("PF", "256"))
 dev = torch.device("cuda:0")
-pcm = bench.synth_batch_gpu(torch, S, F, 44100, dev)
+pcm = bench.synth_batch_gpu(torch, np, S, F, [44100] * S, [0.7] * S, False, dev)
+st = torch.cuda.current_stream().cuda_stream
 b = api.Batch(api.default_control(bitrate=64, short_block_threshold=99999), nstreams=S, max_frames=F)
 b.debug_enable(True)
-host = pcm.cpu().numpy()
-b.encode_host(host)
-b.encode_host(host)
+stride = b.out_stride(F)
+out = torch.empty((S, stride), dtype=torch.uint8, device=dev); nb = torch.zeros((S,), dtype=torch.int32, device=dev)
+for c in range(3):
+    b.encode_device(pcm.data_ptr(), F, out.data_ptr(), stride, nb.data_ptr(), st)
+torch.cuda.synchronize()
 prof = b.debug_read("prof", np.uint64, S * 64).reshape(S, 64).astype(np.float64)
-t = prof[:, 31] / (2 * F)
-print("per-stream ticks/frame: min %.0f mean %.0f p50 %.0f p95 %.0f p99 %.0f max %.0f  max/mean %.3f" % (t.min(), t.mean(), np.median(t), np.percentile(t, 95), np.percentile(t, 99), t.max(), t.max() / t.mean()))
-names = {2: "seek_initial", 3: "seek_actual", 6: "big_lucky", 8: "count_bits", 9: "increase_bits", 10: "decrease_bits", 1: "startup", 13: "pack_huff", 20: "#sweeps", 21: "#lucky", 22: "#count_bits"}
-order = np.argsort(t)
-for label, idx in (("slowest 16", order[-16:]), ("median 16", order[S // 2 - 8:S // 2 + 8]), ("fastest 16", order[:16])):
-    print(label, " ".join("%s=%.0f" % (names[k], prof[idx, k].mean() / (2 * F)) for k in names))
-full = {0: "load xr", 1: "startup", 2: "seek_initial", 3: "seek_actual", 4: "trade_dual", 5: "scale_factors", 6: "big_lucky", 7: "do_quant", 8: "count_bits", 9: "increase_bits", 10: "decrease_bits", 11: "inverse_sf2", 13: "pack_huff", 14: "frame setup", 15: "compute_mask", 16: "pack_sf", 17: "flush+side", 18: "emit"}
-mean = prof.mean(axis=0) / (2 * F)
-for s_ in order[-6:][::-1]:
-    row = prof[s_] / (2 * F)
-    print("stream %4d total %.0f (+%.0f): " % (s_, row[31], row[31] - mean[31]) + " ".join("%s%+.0f" % (full[k], row[k] - mean[k]) for k in full if abs(row[k] - mean[k]) > 300))
-hist, edges = np.histogram(t, bins=12)
-print("histogram:", " ".join("%.0f:%d" % (edges[i], hist[i]) for i in range(12)))
-ms, n = b.alloc_kernel_ms()
-print("k_alloc ms %.3f (%d calls)" % (ms, n))
+names = {0: "join wait", 1: "startup", 2: "seek_initial", 3: "seek_actual", 4: "trade_dual", 5: "scale_factors", 6: "big_lucky", 7: "do_quant", 8: "quant+count", 9: "increase_bits",
+         10: "decrease_bits", 11: "inverse_sf2", 12: "bitallo total", 13: "hand-over", 17: "placement", 20: "#sweeps", 21: "#lucky passes", 22: "#counts", 31: "kernel total"}
+order = np.argsort(prof[:, 31])
+top = order[-10:]
+print("streams by kernel total (k cycles per frame): min %.0f  mean %.0f  p95 %.0f  p99 %.0f  max %.0f" % tuple(x / F / 1e3 for x in (
+    prof[:, 31].min(), prof[:, 31].mean(), np.percentile(prof[:, 31], 95), np.percentile(prof[:, 31], 99), prof[:, 31].max())))
+print("%-16s %10s %10s   slowest streams: %s" % ("per frame", "mean", "slowest10", " ".join(str(int(s)) for s in top[::-1])))
+for k in sorted(names):
+    unit = 1.0 if k >= 20 and k <= 22 else 1.0
+    print("%-16s %10.0f %10.0f   %s" % (names[k], prof[:, k].mean() / F, prof[top, k].mean() / F, " ".join("%6.0f" % (prof[s, k] / F) for s in top[::-1][:6])))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from hmp3_amd import api, synth
-S, F, calls = 1024, 64, 6
+S, F, calls = 1024, int(os.environ.get("PF", "64")), 6
 pcm = synth.batch_pcm(S, F, unique=16)
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
@@ -27,6 +27,11 @@ for mode in ("plain", "submit"):
     prof = b.debug_read("prof", np.uint64, S * 64).reshape(S, 64).astype(np.float64)
     res[mode] = prof
     b.close()
+for m in res:       # wall-clock (100 MHz) start and end of every stream's workgroup in the last launch
+    t0, t1 = res[m][:, 40], res[m][:, 41]
+    z = t0.min()
+    print("%-7s starts: %.3f .. %.3f ms after the first; ends: earliest %.3f, mean %.3f, last %.3f ms; mean duration %.3f ms" % (
+        m, 0.0, (t0.max() - z) / 1e5, (t1.min() - z) / 1e5, (t1.mean() - z) / 1e5, (t1.max() - z) / 1e5, (t1 - t0).mean() / 1e5))
 print("%-20s %12s %12s   (mean cycles per frame; slowest 5%% of the streams in brackets)" % ("", "plain", "submit"))
 slow = {m: np.argsort(res[m][:, 31])[-S // 20:] for m in res}
 for k in sorted(names):
