@@ -1,12 +1,16 @@
 // hx_front.hip - front-end kernels of the batched MP3 encoder for MI355X (gfx950):
 //   k_dcfilter   K0  optional input DC blocker, sequential per channel   (filter2.c:116-144)
-//   k_polyphase  K1  int16 / fp32 PCM -> 32 x 18 subband samples per granule (the stage of sbt.c:57-310)
-//   k_attack_eng K2a subband energies in mB for the transient detector  (detect.c:80-101)
+//   k_polyphase  K1  int16 / fp32 PCM -> 32 x 18 subband samples per granule (the stage of sbt.c:57-310), and in its
+//                    epilogue the subband energies in mB for the transient detector (detect.c:80-101)
+//   k_attack_eng K2a the same energies of the carried granule (the call's first detector index)
 //   k_attack_flg K2b attack metric for both "previous granule short" cases (detect.c:103-141)
 //   k_blocktype  K2c per-stream block-type state machine                (mp3enc.cpp:1398-1440)
 //   k_spec       K4  window + 18-point (3 x 6-point) MDCT + alias butterflies (hwin.c:147-322,
 //                    emdct.c:104-288), MDCT-energy psy model (emap.c:61-96, spdsmr.c:64-273) and the
 //                    L/R vs M/S metric (bitallo3.cpp:682-742, bitallos.cpp:377-416), one wave per granule
+//   k_msscan     K5a the frames' stereo decisions: hysteresis scan over a stream's granules (bitallo3.cpp:693-751)
+//   k_prep       K5b what the allocator's granule start needs that does not depend on its carried state: signs, band
+//                    energies, band maxima of x^(3/4), zero-gain steps, masks (bitallo3.cpp:816-1066, spdsmr.c:275-318)
 //   k_carry      K8  roll the 3-granule subband carry and the PCM history
 // Parallel over streams x channels x granules (x slots / subbands / partitions).  Each lane
 // evaluates its unit with the reference's operation order, so results are bit-identical.
