@@ -50,7 +50,7 @@ EXPORTS = [
     "hx_xing_create", "hx_xing_destroy", "hx_xing_header", "hx_xing_toc", "hx_xing_update_info", "hx_xing_update_crc", "hx_xing_bitrate_index", "hx_batch_status",
     "hx_batch_gate_timeouts", "hx_enc_out_stats", "hx_multi_create", "hx_multi_destroy", "hx_multi_ndevices", "hx_multi_nstreams", "hx_multi_shard", "hx_multi_batch",
     "hx_multi_out_stride", "hx_multi_encode_s16_host", "hx_multi_encode_f32_host", "hx_multi_encode_f32_host_stats", "hx_multi_status",
-    "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
+    "hx_build_id", "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
 ]
 
 _lib = None
@@ -166,6 +166,15 @@ def default_control(**kw):
     if kw.get("bitrate", -1) > 0 and "vbr_flag" not in kw:
         ec.vbr_flag = 0
     return ec
+
+
+def build_id():
+    """hash of the sources / flags the loaded library was built from (None for builds that predate it)"""
+    L = lib()
+    if not hasattr(L, "hx_build_id"):
+        return None
+    L.hx_build_id.restype = C.c_char_p
+    return L.hx_build_id().decode()
 
 
 def last_error():

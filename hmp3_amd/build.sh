@@ -1,21 +1,25 @@
 #!/bin/bash
 # Build the MI355X encoder library in-tree: hmp3_amd/libhmp3amd.so (gfx950 only).
 # -ffp-contract=off: the kernels must not fuse multiply-adds (bit-exactness against the oracle).
+# HX_EXTRA: extra compiler flags (e.g. -DHX_PROFILE); HX_LIBNAME: build a variant library next to the product
+# (objects go to a directory of their own, so variants can be built side by side).
 set -e
 cd "$(dirname "$0")/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 ${HX_OPT:--O3} $HX_EXTRA -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
-$HIPCC $FLAGS -c hx_front.hip -o hx_front.o
-$HIPCC $FLAGS -c hx_alloc.hip -o hx_alloc.o
-$HIPCC $FLAGS -c hx_alloc_lsf.hip -o hx_alloc_lsf.o
-$HIPCC $FLAGS -c hx_alloc1.hip -o hx_alloc1.o
-$HIPCC $FLAGS -c hx_alloc1_lsf.hip -o hx_alloc1_lsf.o
-$HIPCC $FLAGS -c hx_pack.hip -o hx_pack.o
-$HIPCC $FLAGS -c hx_cabi.hip -o hx_cabi.o
-g++ -O2 -fPIC -ffp-contract=off -std=c++17 -c hx_host.cpp -o hx_host.o
-g++ -O2 -fPIC -ffp-contract=off -std=c++17 -c hx_xhead.cpp -o hx_xhead.o
-g++ -O2 -fPIC -ffp-contract=off -std=c++17 -c hx_src.cpp -o hx_src.o
-$HIPCC --offload-arch=gfx950 -shared -o ../${HX_LIBNAME:-libhmp3amd.so} hx_front.o hx_alloc.o hx_alloc_lsf.o hx_alloc1.o hx_alloc1_lsf.o hx_pack.o hx_cabi.o hx_host.o hx_xhead.o hx_src.o
-rm -f *.o
+LIB=${HX_LIBNAME:-libhmp3amd.so}
+OBJ=$(mktemp -d /tmp/hxbuild.XXXXXX)
+trap 'rm -rf "$OBJ"' EXIT
+# build id = hash of the kernel / host sources and of the flags that change the generated code
+BUILD_ID=$( (cat *.hip *.inc *.h *.cpp; echo "${HX_OPT:--O3} $HX_EXTRA") | sha256sum | cut -c1-16)
+FLAGS="-DHX_BUILD_ID=\"$BUILD_ID\" --offload-arch=gfx950 ${HX_OPT:--O3} $HX_EXTRA -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
+pids=()
+for f in hx_front hx_alloc hx_alloc_lsf hx_alloc1 hx_alloc1_lsf hx_pack hx_cabi; do
+  $HIPCC $FLAGS -c $f.hip -o $OBJ/$f.o & pids+=($!)
+done
+for f in hx_host hx_xhead hx_src; do
+  g++ -O2 -fPIC -ffp-contract=off -std=c++17 -c $f.cpp -o $OBJ/$f.o & pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -o ../$LIB $OBJ/*.o
 [ -n "$HX_LIBNAME" ] || g++ -O2 -std=c++17 -Wall ../cli/hmp3amd.cpp -o ../hmp3amd -L.. -lhmp3amd -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
-echo built hmp3_amd/libhmp3amd.so hmp3_amd/hmp3amd
+echo built hmp3_amd/$LIB build_id=$BUILD_ID

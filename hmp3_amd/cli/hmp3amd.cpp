@@ -322,12 +322,17 @@ int encode_streaming(const char *fin, const char *fout, const Options &opt)
             if (hi - lo < (size_t) init_bytes && !(eof && zeros_left == 0)) {      // refill
                 memmove(win.data(), win.data() + lo, hi - lo);
                 hi -= lo; lo = 0;
-                while (hi < piece && !(eof && zeros_left == 0)) {
+                while (hi + 8 <= piece && !(eof && zeros_left == 0)) {     // (less than a sample's room left counts as full)
                     if (!eof) {
                         size_t want = piece - hi;
                         if ((uint64_t) want > indatasize - audio) want = (size_t) (indatasize - audio);
+                        else {      // every piece ends on a sample boundary of the data (24-bit samples do not divide 1 MiB), so
+                                    // that the byte swap of big-endian input never tears a sample; the data's torn tail is padding
+                            const size_t bsz = (size_t) std::max(in.wi.bits / 8, 1), over = (size_t) ((audio + want) % bsz);
+                            if (want > over) want -= over;
+                        }
                         const size_t got = want ? fread(win.data() + hi, 1, want, fi) : 0;
-                        to_host_order(in.wi, win.data() + hi, got);     // (pieces are whole samples: 1 MiB is a multiple of 1..4-byte samples; a torn last sample is padding anyway)
+                        to_host_order(in.wi, win.data() + hi, got);
                         hi += got; audio += got;
                         if (got < want || audio >= indatasize) eof = true;
                     } else {
@@ -538,7 +543,17 @@ int main(int argc, char **argv)
         case 'v': ec.vbr_flag = 1; ec.vbr_mnr = atoi(a + 2); break;
         case 'l': ec.vbr_br_limit = atoi(a + 2); break;
         case 'a': opt.mpeg_select = atoi(a + 2); if (opt.mpeg_select < 0) opt.mpeg_select = 0; break;
-        default: break;             // -W and unknown switches: ignored like the reference does
+        case 'w': {                 // -W<file>: 21 per-band MNR offsets (tomp3.cpp:552-555, get_mnr_adjust :1203-1233)
+            FILE *f = fopen(a + 2, "rt");
+            if (!f) break;          // (the reference ignores a file it cannot open)
+            for (int k = 0; k < 21; k++) ec.mnr_adjust[k] = 0;
+            for (int k = 0, m = 0; k < 21 && fscanf(f, "%d", &m) == 1; k++) ec.mnr_adjust[k] = m;
+            fclose(f);
+            fprintf(stderr, "\nMNR adjust ");
+            for (int k = 0; k < 21; k++) { ec.mnr_adjust[k] = std::max(-200, std::min(200, ec.mnr_adjust[k])); fprintf(stderr, " %d", ec.mnr_adjust[k]); }
+            break;
+        }
+        default: break;             // unknown switches: ignored like the reference does
         }
     }
     opt.ec.vbr_flag = opt.ec.bitrate < 0 ? 1 : 0;

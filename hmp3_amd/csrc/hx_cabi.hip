@@ -39,6 +39,15 @@ __global__ void k_alloc(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
 __global__ void k_alloc1(AllocArgs a);
 __global__ void k_alloc1_lsf(AllocArgs a);
+extern "C" int k_alloc_lds_bytes();
+extern "C" int k_alloc_lsf_lds_bytes();
+extern "C" int k_alloc1_lds_bytes();
+extern "C" int k_alloc1_lsf_lds_bytes();
+#ifdef HX_DYN_LDS
+#define K6_LDS(name) ((size_t) name##_lds_bytes())
+#else
+#define K6_LDS(name) ((size_t) 0)
+#endif
 
 static thread_local std::string g_err;
 static void set_err(const char *fmt, const char *a = "")
@@ -51,8 +60,9 @@ static void set_err(const char *fmt, const char *a = "")
 #define HIPCHKN(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("HIP error: %s", hipGetErrorString(e_)); return nullptr; } } while (0)
 // every kernel launch is checked where it is made: a bad configuration or a lost device is reported
 // with the kernel's name instead of surfacing at some later call
-#define LAUNCH(kernel, grid, block, stream, ...) do { hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); \
+#define LAUNCH_LDS(kernel, grid, block, lds, stream, ...) do { hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); \
         hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err("launch of " #kernel " failed: %s", hipGetErrorString(e_)); return -1; } } while (0)
+#define LAUNCH(kernel, grid, block, stream, ...) LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)
 
 struct hx_batch {
     int device = 0, S = 0, maxF = 0, ncls = 0;
@@ -125,10 +135,18 @@ struct hx_batch {
     // Not 100: the gate's own wavefront holds register space on one SIMD, so the last allocator workgroup of a full
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
+    bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
     int lpt = 1;                        // longest-first workgroup order: 1 = for batches beyond the resident set, 0 = never, 2 = always (HMP3AMD_LPT; tests)
 };
 
 extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
+
+// hash of the sources this library was built from (hmp3_amd/build.sh passes it): profiles/ and bench.py use it to tell
+// whether committed counter profiles belong to the loaded build
+#ifndef HX_BUILD_ID
+#define HX_BUILD_ID "unknown"
+#endif
+extern "C" const char *hx_build_id(void) { return HX_BUILD_ID; }
 
 extern "C" int hx_device_count(void)
 {
@@ -145,7 +163,9 @@ extern "C" void hx_batch_destroy(hx_batch *b)
 {
     if (!b) return;
     hipSetDevice(b->device);
-    if (b->s_pack) flush_pack(b, -1);
+    // A packing that was never asked for (no hx_batch_wait / plain call / status read after the last device-buffer submit)
+    // is dropped, not enqueued: it would write into output buffers the caller may have freed already.
+    b->pack_job.pending = false;
     hipDeviceSynchronize();
     void *ptrs[] = {b->d_prm, b->d_gt, b->d_st, b->d_sb, b->d_xr, b->d_etab, b->d_thr, b->d_eng, b->d_msbase,
                     b->d_status, b->d_dbgmetric, b->d_flg, b->d_bt, b->d_btprev, b->d_dbg, b->d_pcm, b->d_out, b->d_outbytes, b->d_pcmf, b->d_prof,
@@ -257,7 +277,8 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         int per_cu = 0;
         HIPCHKN(hipGetDeviceProperties(&prop, device));
         const void *kern = b->alloc1 ? (b->lsf ? (const void *) k_alloc1_lsf : (const void *) k_alloc1) : (b->lsf ? (const void *) k_alloc_lsf : (const void *) k_alloc);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 128, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        const size_t dyn = b->alloc1 ? (b->lsf ? K6_LDS(k_alloc1_lsf) : K6_LDS(k_alloc1)) : (b->lsf ? K6_LDS(k_alloc_lsf) : K6_LDS(k_alloc));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 128, dyn) != hipSuccess || per_cu <= 0) per_cu = 4;
         b->resident = per_cu * prop.multiProcessorCount;
     }
     if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 1152 * b->nchan);
@@ -420,6 +441,7 @@ static int pipe_init(hx_batch *b)
 static int check_call(const hx_batch *b, const void *pcm, int nframes, const void *out, long long out_stride, const void *out_bytes)
 {
     if (!b) { set_err("null batch"); return -1; }
+    if (b->poisoned) { set_err("the batch is unusable after a failed device call: destroy it"); return -1; }
     if (nframes <= 0 || nframes > b->maxF) { set_err("nframes out of range (1 .. max_frames of hx_batch_create)"); return -1; }
     if (!pcm || !out || !out_bytes) { set_err("null buffer"); return -1; }
     if (out_stride < hx_batch_out_stride(b, nframes)) { set_err("out_stride is smaller than hx_batch_out_stride(b, nframes)"); return -1; }
@@ -467,16 +489,30 @@ static int flush_pack(hx_batch *b, long long gate_base)
 // one pass of the pipeline over the batch; the input is int16 (d_pcm) or fp32 at int16 scale (d_pcm32).
 // pipelined = 0: every kernel on the caller's stream.  pipelined = 1 (hx_batch_submit_*): front end
 // and k_alloc on the batch's own two streams, ordered by events (see hx_batch).
+static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, int nframes, unsigned char *d_out,
+                       long long out_stride, int *d_out_bytes, void *stream, int pipelined);
 static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, int nframes, unsigned char *d_out,
                        long long out_stride, int *d_out_bytes, void *stream, int pipelined = 0)
 {
     if (check_call(b, d_pcm ? (const void *) d_pcm : (const void *) d_pcm32, nframes, d_out, out_stride, d_out_bytes) != 0) return -1;
+    const int r = encode_pass(b, d_pcm, d_pcm32, nframes, d_out, out_stride, d_out_bytes, stream, pipelined);
+    // A launch or HIP call that fails inside a pass leaves events unrecorded and buffer sets half handed over: the batch is
+    // not reusable (this only happens on a device error).  Later calls are refused; hx_batch_destroy just synchronises.
+    if (r != 0) b->poisoned = true;
+    return r;
+}
+static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, int nframes, unsigned char *d_out,
+                       long long out_stride, int *d_out_bytes, void *stream, int pipelined)
+{
     hipStream_t q = (hipStream_t) stream, qa = q;
     HIPCHK(hipSetDevice(b->device));
-    int set = 0;
+    int set = 0, flushed_set = -1;
     if (pipelined) {
         if (pipe_init(b) != 0) return -1;
-        if (pipelined == 2 && flush_pack(b, -1) != 0) return -1;    // (a host-buffer submit behind device-buffer ones)
+        if (pipelined == 2 && b->pack_job.pending) {                // (a host-buffer submit behind device-buffer ones)
+            flushed_set = b->pack_job.set;
+            if (flush_pack(b, -1) != 0) return -1;
+        }
         set = (int) (b->nsubmit & 1);
         HIPCHK(hipEventRecord(b->ev_in, q));                        // the caller's PCM is ready from here on
         HIPCHK(hipStreamWaitEvent(b->s_front, b->ev_in, 0));
@@ -574,9 +610,9 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, qa));
-    if (b->alloc1) { if (b->lsf) LAUNCH(k_alloc1_lsf, dim3(S), dim3(128), qa, a); else LAUNCH(k_alloc1, dim3(S), dim3(128), qa, a); }
-    else if (b->lsf) LAUNCH(k_alloc_lsf, dim3(S), dim3(128), qa, a);
-    else LAUNCH(k_alloc, dim3(S), dim3(128), qa, a);
+    if (b->alloc1) { if (b->lsf) LAUNCH_LDS(k_alloc1_lsf, dim3(S), dim3(128), K6_LDS(k_alloc1_lsf), qa, a); else LAUNCH_LDS(k_alloc1, dim3(S), dim3(128), K6_LDS(k_alloc1), qa, a); }
+    else if (b->lsf) LAUNCH_LDS(k_alloc_lsf, dim3(S), dim3(128), K6_LDS(k_alloc_lsf), qa, a);
+    else LAUNCH_LDS(k_alloc, dim3(S), dim3(128), K6_LDS(k_alloc), qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
     // Every frame of the call packed at once, between the pending frames' images coming out of the stream state and the
@@ -591,6 +627,9 @@ static int encode_core(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         j.pending = true; j.d_out = d_out; j.out_stride = out_stride; j.d_out_bytes = d_out_bytes; j.nframes = nframes; j.set = set; j.sset = sset;
     } else {
         if (pipelined) HIPCHK(hipEventRecord(b->ev_k6[set], qa));
+        // the previous device-buffer submit's packing went out on the packing stream above: its k_pack_carry writes the
+        // carried frame images that this call's k_pack_pre reads
+        if (flushed_set >= 0) HIPCHK(hipStreamWaitEvent(qa, b->ev_alloc[flushed_set], 0));
         if (enqueue_pack(b, d_out, out_stride, d_out_bytes, nframes, set, sset, qa) != 0) return -1;
         if (pipelined) { HIPCHK(hipEventRecord(b->ev_alloc[set], qa)); HIPCHK(hipEventRecord(b->ev_sgn[sset], qa)); }
     }
@@ -817,13 +856,14 @@ extern "C" int hx_batch_encode_f32_host(hx_batch *b, const float *pcm, int nfram
 
 extern "C" int hx_batch_status(hx_batch *b)
 {
-    int v = -1, gate[2] = {0, 0};
+    int v = -1;
     if (!b) return -1;
+    if (b->poisoned) return -1;
     hipSetDevice(b->device);
     if (b->s_pack) flush_pack(b, -1);
     hipDeviceSynchronize();
+    // (a gate that gave up waiting costs overlap, not correctness: it is counted in hx_batch_gate_timeouts, not here)
     if (hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (hipMemcpy(gate, b->d_done, sizeof(gate), hipMemcpyDeviceToHost) == hipSuccess && gate[1] > 0) v |= 8;
     return v;
 }
 

@@ -172,11 +172,15 @@ int hx_batch_encode_f32_host_stats(hx_batch *b, const float *pcm, int nframes, u
 int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *head_out);
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
    there), 4 = the Huffman bits packed for a channel differ from the bits counted for it (an internal
-   consistency check of the two-wave packer), 8 = the gate of a pipelined submit gave up waiting at least
-   once (results are correct, the overlap was lost; hx_batch_gate_timeouts counts them).  0 = healthy.
-   Synchronises. */
+   consistency check of the two-wave packer).  0 = healthy; -1 = no answer (the batch became unusable after a
+   failed device call, or the status could not be read).  Synchronises.
+   hx_batch_gate_timeouts: how many pipelined submits started their front end late because the gate on the previous
+   allocator launch gave up waiting (results are correct, overlap was lost; a loaded or profiled GPU can cause it).
+   It is a performance counter, not part of the health status. */
 int hx_batch_status(hx_batch *b);
 int hx_batch_gate_timeouts(hx_batch *b);
+/* identifies the build: a hash of the library's sources and code-generation flags (hmp3_amd/build.sh) */
+const char *hx_build_id(void);
 /* total frames / bytes emitted so far by stream i (synchronises) */
 HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int stream_index);
 /* mean device time of the dominant (allocator) kernel over the calls since the last query, in

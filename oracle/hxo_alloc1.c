@@ -2,7 +2,9 @@
  * reference still uses where the newer one cannot go: joint stereo with intensity coding (MPEG-1 below 96 kbps,
  * MPEG-2 below 48 kbps total) and dual-channel mode.  Long blocks only, CBR only.  Restates
  * bitallo1.cpp:100-1813 (class CBitAllo1); every floating-point expression in the reference's order and
- * precision (float vs double as written there). */
+ * precision.  The reference file is C++: log10 / log / sqrt of a float argument there resolve to the float
+ * overloads (log10f, logf, sqrtf of libm - checked in the object code: smr_adj, smr_adj_joint, compute_x34,
+ * fnc_noise2 and fnc_noise2_cb call them), and the arithmetic around them stays in float where every operand is. */
 #include <math.h>
 #include <string.h>
 #include "hxo_int.h"
@@ -154,7 +156,7 @@ static void smr_adj(a1_t *b, hxo_sigmask sm[][36], unsigned char signx[][576])
             for (i = 0; i < nsf[ch]; i++) {
                 r = sm[ch][i].sig / (sm[ch][i].mask * (0.1f + 0.0001f * b->xsxx[ch][i]));
                 if (r < 1.0e-10f) b->mask[ch][i] = 100.0f;
-                else b->mask[ch][i] = (float) (-10.0 * log10(r) - t->look_log_cbw[i]);
+                else b->mask[ch][i] = (float) (-10.0 * log10f(r) - t->look_log_cbw[i]);
             }
         return;
     }
@@ -216,11 +218,11 @@ static void smr_adj(a1_t *b, hxo_sigmask sm[][36], unsigned char signx[][576])
             if (xr[0][k] < 0.0f) { signx[0][k] = 1; xr[0][k] = -xr[0][k]; }
         }
         if (b->p->h_id) {
-            r = (float) (sqrt((b->xsxx[0][i] + b->xsxx[1][i] + 2.0 * sqrt(b->xsxx[0][i] * b->xsxx[1][i])) / r));
+            r = (float) (sqrt((b->xsxx[0][i] + b->xsxx[1][i] + 2.0 * sqrtf(b->xsxx[0][i] * b->xsxx[1][i])) / r));
             if (r > 1.5f) r = 1.5f;
         } else {
             aa = (b->xsxx[0][i] > b->xsxx[1][i]) ? b->xsxx[0][i] : b->xsxx[1][i];
-            r = (float) (sqrt(aa / r));
+            r = (float) (sqrtf(aa / r));
             if (r > 1.2f) r = 1.2f;
         }
         k = t->startBand[i];
@@ -230,12 +232,12 @@ static void smr_adj(a1_t *b, hxo_sigmask sm[][36], unsigned char signx[][576])
         for (i = 0; i < nsf[1]; i++) {
             r = sm[ch][i].sig / (sm[ch][i].mask * (0.1f + 0.0001f * b->xsxx[ch][i]));
             if (r < 1.0e-10f) b->mask[ch][i] = 100.0f;
-            else b->mask[ch][i] = (float) (-10.0 * log10(r) - t->look_log_cbw[i]);
+            else b->mask[ch][i] = (float) (-10.0 * log10f(r) - t->look_log_cbw[i]);
         }
     for (i = nsf[1]; i < nsf[0]; i++) {
         r = (sm[0][i].sig + sm[1][i].sig) / ((sm[0][i].mask + sm[1][i].mask) * (0.1f + 0.0001f * (b->xsxx[0][i] + b->xsxx[1][i])));
         if (r < 1.0e-10f) b->mask[0][i] = 100.0f;
-        else b->mask[0][i] = (float) (-10.0 * log10(r) - t->look_log_cbw[i]);
+        else b->mask[0][i] = (float) (-10.0 * log10f(r) - t->look_log_cbw[i]);
     }
     /* the intensity position of each band rides in the right channel's scalefactor */
     for (i = nsf[1]; i < nsf[0]; i++) {
@@ -267,7 +269,7 @@ static void compute_x34(a1_t *b)
             for (j = 0; j < n; j++, k++) if (b->x34max[ch][i] < b->x34[ch][k]) b->x34max[ch][i] = b->x34[ch][k];
             if (b->x34mm < b->x34max[ch][i]) b->x34mm = b->x34max[ch][i];
             if (b->x34max[ch][i] < t->gz_con0) b->gzero[ch][i] = 0;
-            else b->gzero[ch][i] = (int) (t->gz_con1 * log(b->x34max[ch][i]) + t->gz_con2);
+            else b->gzero[ch][i] = (int) (t->gz_con1 * logf(b->x34max[ch][i]) + t->gz_con2);
             b->gmin[ch][i] = HXO_MAX(0, b->gzero[ch][i] - GMIN_OFFSET);
         }
     }
@@ -391,7 +393,7 @@ static void fnc_noise2_cb(a1_t *b, int i, int ch)
             sum += t->look_f_big_ix[ixm];
         }
     }
-    b->noise[ch][i] = (float) (10.0f * log10(sum) - t->look_log_cbw[i] + 1.505f * gsf);
+    b->noise[ch][i] = (float) (10.0f * log10f(sum) - t->look_log_cbw[i] + 1.505f * gsf);
 }
 
 static void fnc_noise2(a1_t *b)

@@ -11,6 +11,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <malloc.h>
 #define private public
 #define protected public
 #include "mp3enc.h"
@@ -35,8 +36,11 @@ int ref_src_convert(void *h, unsigned char *xin, float *yout, int *out_bytes)
     return x.in_bytes;
 }
 /* CMp3Enc::MP3_audio_encode_init / MP3_audio_encode with every argument */
+struct ZeroHeap;
 int ref_init_mp3(void *h, E_CONTROL *ec, int bits, int is_float, int mpeg_select, int mono_convert)
 {
+    mallopt(M_PERTURB, 0xFF);
+    struct Restore { ~Restore() { mallopt(M_PERTURB, 0); } } restore;
     return ((CMp3Enc *) h)->MP3_audio_encode_init(ec, bits, is_float, mpeg_select, mono_convert);
 }
 int ref_encode_mp3(void *h, unsigned char *pcm, unsigned char *out, int *in_bytes)
@@ -46,10 +50,17 @@ int ref_encode_mp3(void *h, unsigned char *pcm, unsigned char *out, int *in_byte
     return x.out_bytes;
 }
 
-void *ref_new(void) { return new CMp3Enc; }
+/* The reference reads members that its constructors and init functions never set (found by tools/fuzz_oracle_vs_ref.py
+ * --a1: the first-generation allocator's output for impulses on silence depended on what earlier encoders of the
+ * process had left on the heap).  A process that creates one encoder - the reference's own command line - gets them
+ * from fresh, zero-filled pages; this harness pins that behaviour for every encoder it creates: while the encoder
+ * object and the objects its init function allocates are created, glibc's allocator hands out zero-filled blocks
+ * (M_PERTURB with 0xFF fills an allocated block with the complement, 0x00). */
+struct ZeroHeap { ZeroHeap() { mallopt(M_PERTURB, 0xFF); } ~ZeroHeap() { mallopt(M_PERTURB, 0); } };
+void *ref_new(void) { ZeroHeap z; return new CMp3Enc; }
 void ref_free(void *h) { delete (CMp3Enc *) h; }
-int ref_init(void *h, E_CONTROL *ec) { return ((CMp3Enc *) h)->L3_audio_encode_init(ec); }
-int ref_init_s16(void *h, E_CONTROL *ec) { return ((CMp3Enc *) h)->MP3_audio_encode_init(ec, 16, 0, 0, 0); }
+int ref_init(void *h, E_CONTROL *ec) { ZeroHeap z; return ((CMp3Enc *) h)->L3_audio_encode_init(ec); }
+int ref_init_s16(void *h, E_CONTROL *ec) { ZeroHeap z; return ((CMp3Enc *) h)->MP3_audio_encode_init(ec, 16, 0, 0, 0); }
 int ref_encode(void *h, float *pcm, unsigned char *out) { return ((CMp3Enc *) h)->L3_audio_encode(pcm, out).out_bytes; }
 int ref_encode_packet(void *h, float *pcm, unsigned char *out, unsigned char *packet, int *nbytes)
 {

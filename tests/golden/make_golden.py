@@ -31,6 +31,22 @@ STREAM_CASES = {
     "vbr50_default_bursts": (dict(), 44100, 40, 0.7, True),
 }
 
+# streams whose signal is more than a seed: name -> (E_CONTROL overrides, sample rate, frames, seed, rho, bursts, amplitude, right = -left)
+# a1_dual_16k_antiphase: dual channel at 2 x 8 kbps, the first-generation allocator; with the double-precision log10 the
+# reference does NOT use there (bitallo1.cpp is C++: log10f) an encoder codes one more line in the second frame
+EXTRA_CASES = {
+    "a1_dual_16k_antiphase": (dict(samprate=16000, mode=2, bitrate=8), 16000, 40, 181220, 1.0, True, 0.25, True),
+}
+
+
+def extra_case_pcm(name):
+    kw, sr, nfr, seed, rho, bursts, amp, anti = EXTRA_CASES[name]
+    pcm = synth.stream_pcm(seed, nfr, sr=sr, rho=rho, bursts=bursts)
+    pcm = (pcm.astype(np.float64) * amp).astype(np.int16)
+    if anti:
+        pcm[:, 1] = -pcm[:, 0]
+    return pcm
+
 
 def main():
     r = O.ref()
@@ -117,6 +133,11 @@ def main():
                                         initialMNR=d.initialMNR, nsf=list(d.nsf)),
                           state=state)
         print("%-26s %6d bytes, %d frames" % (name, sum(sizes), nfr))
+    for name, (kw, sr, nfr, seed, rho, bursts, amp, anti) in EXTRA_CASES.items():
+        data = O.encode_stream(O.RefEncoder(O.default_control(**kw)), extra_case_pcm(name))
+        with open(os.path.join(GOLD, name + ".mp3frames"), "wb") as fh:
+            fh.write(data)
+        print("%-26s %6d bytes, %d frames" % (name, len(data), nfr))
     with open(os.path.join(GOLD, "streams.json"), "w") as fh:
         json.dump(meta, fh)
     print("golden vectors written to", GOLD)

@@ -40,6 +40,7 @@ CASES = {
     "cli_rf64_vbr50_s16_48k": (916, 30013, 48000, False, True, []),                   # ds64 chunk, data size 0xFFFFFFFF
     "cli_w64_cbr64_s24_44k": (917, 30001, 44100, 24, False, ["-B64"]),                # Sony Wave64 GUID chunks
     "cli_ext_vbr60_s24_48k": (918, 30007, 48000, 24, False, ["-V60"]),                # WAVE_FORMAT_EXTENSIBLE + a LIST chunk
+    "cli_rifx_cbr64_s24_44k": (931, 200003, 44100, 24, False, ["-B64"]),            # big-endian 24-bit, more than 1 MiB of samples (a streaming reader's pieces must not tear a sample)
     "cli_odd_cbr64_u8_mono_44k": (919, 30001, 44100, 8, False, ["-B64"]),             # odd data size: the pad byte counts
     # sample-rate conversion in front of the encoder (Csrc cases 1-4; -A picks the encode rate)
     "cli_src_11k_to_22k_s16": (920, 20001, 11025, False, True, ["-B32"]),                 # 1:2 up
@@ -55,7 +56,7 @@ CASES = {
     "cli_dual_cbr128_s24_44k": (929, 50021, 44100, 24, True, ["-B64", "-M2"]),
     "cli_dual_lsf_cbr48_s16_24k": (930, 40009, 24000, False, False, ["-B24", "-M2"]),
 }
-CONTAINER = {"cli_rifx_cbr64_s16_44k": "rifx", "cli_rf64_vbr50_s16_48k": "rf64", "cli_w64_cbr64_s24_44k": "w64",
+CONTAINER = {"cli_rifx_cbr64_s16_44k": "rifx", "cli_rifx_cbr64_s24_44k": "rifx", "cli_rf64_vbr50_s16_48k": "rf64", "cli_w64_cbr64_s24_44k": "w64",
              "cli_ext_vbr60_s24_48k": "ext"}
 MONO = {"cli_odd_cbr64_u8_mono_44k", "cli_src_8k_to_16k_u8_mono", "cli_mono_cbr64_s16_44k", "cli_mono_vbr60_f32_48k", "cli_lsf_mono_cbr24_s16_16k"}
 

@@ -125,7 +125,7 @@ def test_bench_configs_verify_against_oracle_at_reduced_size(cfg):
     assert line["verified_streams"] == 12, line["verify"]
 
 
-@pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr50_s24_44k", "cli_lsf_vbr50_f32_24k", "cli_rifx_cbr64_s16_44k"])
+@pytest.mark.parametrize("name", ["cli_cbr128_s16_44k", "cli_vbr50_s24_44k", "cli_lsf_vbr50_f32_24k", "cli_rifx_cbr64_s16_44k", "cli_rifx_cbr64_s24_44k"])
 def test_cli_streams_from_a_pipe_with_bounded_buffers(name, tmp_path):
     """`hmp3amd - out.mp3`: the input arrives on a pipe and is encoded frame by frame through a sliding window
     (memory independent of the input length); the file equals the one the reference CLI wrote from the WAV."""
@@ -250,3 +250,74 @@ def test_submit_path_for_every_stream_type(kw, nch):
         for s in range(S):
             assert got[c][s] == want[c][s], "call %d stream %d" % (c, s)
     b.close()
+
+
+@pytest.mark.parametrize("args", [["120", "501"], ["--submit", "80", "502"], ["--a1", "60", "503"]], ids=["host_calls", "overlapped_submits", "first_generation_allocator"])
+def test_fuzz_parity_slice(args):
+    """fixed-seed slices of tools/fuzz_parity.py (the sweep that found the round-2 bit-writer defect): random controls x
+    random and extreme signals in random-sized calls, GPU against the oracle"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_fuzz_mixed_class_batches_slice():
+    """ten batches of tools/fuzz_mixed.py: every stream of a batch with its own control"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_mixed.py"), "10", "504"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_host_submit_behind_device_submits_sees_their_carried_frames():
+    """A host-buffer submit right behind device-buffer submits on a small batch: the earlier submit's packing (which saves
+    the incomplete frames' images into the stream state) goes out on the packing stream, and the host submit's own
+    packing must wait for it (a missing wait let k_pack_pre read stale images)."""
+    import torch
+    a = api()
+    S, F, calls = 6, 4, 6
+    kw = dict(bitrate=64)
+    pcm = np.stack([synth.stream_pcm(9900 + i, F * calls, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for trial in range(8):
+        b = a.Batch(a.default_control(**kw), nstreams=S, max_frames=F)
+        stride = b.out_stride(F)
+        got = [b"" for _ in range(S)]
+        keep = []
+        host = []
+        for c in range(calls):
+            blk = np.ascontiguousarray(pcm[:, c * F * 1152:(c + 1) * F * 1152])
+            if c % 2 == 0:      # device-buffer submit
+                d_pcm = torch.from_numpy(blk).to(dev)
+                d_out = torch.zeros((S, stride), dtype=torch.uint8, device=dev); d_nb = torch.zeros((S,), dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                b.submit_device(d_pcm.data_ptr(), F, d_out.data_ptr(), stride, d_nb.data_ptr(), st)
+                keep.append((c, d_pcm, d_out, d_nb))
+            else:               # host-buffer submit straight behind it
+                h_pcm = torch.from_numpy(blk).pin_memory()
+                h_out = torch.zeros((S, stride), dtype=torch.uint8).pin_memory(); h_nb = torch.zeros((S,), dtype=torch.int32).pin_memory()
+                b.submit_host(h_pcm.data_ptr(), F, h_out.data_ptr(), stride, h_nb.data_ptr())
+                host.append((c, h_pcm, h_out, h_nb))
+        b.wait(st); b.wait_host(); torch.cuda.synchronize()
+        assert b.status() == 0
+        parts = {}
+        for c, _, o, nb in keep + host:
+            o, nb = o.cpu().numpy(), nb.cpu().numpy()
+            parts[c] = [o[s, :nb[s]].tobytes() for s in range(S)]
+        for s in range(S):
+            assert b"".join(parts[c][s] for c in range(calls)) == oracle_bytes(kw, pcm[s], F * calls), (trial, s)
+        b.close()
+
+
+def test_cli_mnr_adjust_file_switch(tmp_path):
+    """-W<file> (test/tomp3.cpp:552-555, get_mnr_adjust): 21 per-band offsets, clamped to +-200 and echoed; the reference
+    encoder never reads them (bitallo3.cpp:441 is commented out), so the file equals the one written without the switch"""
+    sys.path.insert(0, GOLD)
+    import make_golden_cli as M
+    name = "cli_cbr128_s16_44k"
+    seed, nsamp, sr, as_float, bursts, flags = M.CASES[name]
+    wav, mp3, adj = str(tmp_path / "in.wav"), str(tmp_path / "out.mp3"), str(tmp_path / "adj.txt")
+    M.write_wav(wav, M.case_pcm(name), sr, as_float, M.CONTAINER.get(name))
+    open(adj, "w").write("10 -300 250 7\n")
+    r = subprocess.run([os.path.join(ROOT, "hmp3_amd", "hmp3amd"), wav, mp3] + flags + ["-W" + adj], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    assert b"MNR adjust  10 -200 200 7 0 0" in r.stderr
+    assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()

@@ -112,3 +112,14 @@ def test_no_gpu_means_loud_failure_not_fallback():
         api.Batch(api.default_control(bitrate=64), nstreams=2, max_frames=2)
     e = api.Mp3Enc()
     assert e.L3_audio_encode_init(api.default_control(bitrate=64)) == 0
+
+
+def test_libm32_restatement_equals_this_machines_libm(tmp_path):
+    """hmp3_amd/csrc/hx_libm32.h (what the first-generation allocator's kernels use for the reference's log10f / logf
+    calls) against the libm the oracle and the reference link with, on every 997th positive normal float
+    (tools/check_libm32.c without -DSTEP checks all of them)"""
+    import subprocess
+    exe = str(tmp_path / "check_libm32")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-DSTEP=997", "-o", exe, os.path.join(ROOT, "tools", "check_libm32.c"), "-lm"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout

@@ -121,3 +121,20 @@ def test_silence_and_full_scale_edge_inputs():
     fr = np.stack([sq, -sq - 1], axis=1).astype(np.int16)
     total = sum(len(enc.encode_s16(fr)) for _ in range(12))
     assert total > 0
+
+
+def _extra():
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden as M
+    return M
+
+
+@pytest.mark.parametrize("name", ["a1_dual_16k_antiphase"])
+def test_extra_golden_streams(name):
+    """streams whose signal is more than a seed (make_golden.EXTRA_CASES): the first-generation allocator's dual-channel
+    case that separates libm's log10f (what the reference's C++ calls) from the double log10"""
+    M = _extra()
+    kw = M.EXTRA_CASES[name][0]
+    got = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), M.extra_case_pcm(name))
+    assert got == open(os.path.join(GOLD, name + ".mp3frames"), "rb").read()

@@ -6,9 +6,13 @@ import numpy as np
 from hmp3_amd import synth
 from oracle import oracle as O
 assert O.ref() is not None, "make -C oracle ref first"
+A1 = "--a1" in sys.argv        # only configurations of the first-generation allocator: dual channel, or joint stereo at low bit rates
+if A1:
+    sys.argv.remove("--a1")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 RATES = [16000, 22050, 24000, 32000, 44100, 48000]
+
 bad = done = tried = 0
 while done < n_cases and tried < 30 * n_cases:
     tried += 1
@@ -16,11 +20,16 @@ while done < n_cases and tried < 30 * n_cases:
     kw = dict(samprate=sr, mode=int(rs.choice([0, 0, 1, 1, 1, 2, 3])))
     if rs.rand() < 0.5: kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
     else: kw["vbr_mnr"] = int(rs.randint(0, 151))
+    if A1:
+        kw.pop("vbr_mnr", None)
+        kw["mode"] = int(rs.choice([1, 2, 2]))
+        kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40] if (kw["mode"] == 1 or sr < 32000) else [16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
     if rs.rand() < 0.3: kw["hf_flag"] = int(rs.choice([1, 3]))
     if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000, 21000]))
     if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
     if rs.rand() < 0.15: kw["filter_select"] = 1
     if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
+    if rs.rand() < 0.15: kw["nsb_limit"] = int(rs.choice([4, 8, 12, 16, 20, 24, 28, 31]))
     ok_o = O.OracleEncoder(O.default_control(**kw)).ok()
     r = O.RefEncoder(O.default_control(**kw))
     ok_r = r.bytes_in > 0
@@ -30,10 +39,13 @@ while done < n_cases and tried < 30 * n_cases:
     if not ok_r:
         continue
     F = int(rs.choice([10, 20, 40]))
-    pcm = synth.stream_pcm(int(rs.randint(0, 1 << 20)), F, sr=sr, rho=float(rs.choice([0.0, 0.3, 0.7, 1.0])), bursts=bool(rs.rand() < 0.6))
-    pcm = (pcm.astype(np.float64) * float(rs.choice([1.0, 1.0, 0.25, 0.02]))).astype(np.int16)
+    sig = dict(seed=int(rs.randint(0, 1 << 20)), rho=float(rs.choice([0.0, 0.3, 0.7, 1.0])), bursts=bool(rs.rand() < 0.6))
+    pcm = synth.stream_pcm(sig["seed"], F, sr=sr, rho=sig["rho"], bursts=sig["bursts"])
+    sig["amp"] = float(rs.choice([1.0, 1.0, 0.25, 0.02]))
+    pcm = (pcm.astype(np.float64) * sig["amp"]).astype(np.int16)
     n = F * 1152
     kind = int(rs.randint(0, 12))
+    sig["kind"] = kind
     if kind == 0: pcm[:] = 0
     elif kind == 1: pcm[:] = np.where((np.arange(n) // int(rs.randint(2, 200))) % 2 == 0, 32767, -32768).astype(np.int16)[:, None]
     elif kind == 2: pcm[:] = rs.randint(-32768, 32768, size=(n, 2)).astype(np.int16)
@@ -46,7 +58,12 @@ while done < n_cases and tried < 30 * n_cases:
     a = O.encode_stream(r, pcm)
     b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
     if a != b:
-        print("MISMATCH", kw, len(a), len(b)); bad += 1
+        import hashlib
+        print("MISMATCH", kw, len(a), len(b), "F", F, sig, "md5 reference", hashlib.md5(a).hexdigest()[:8], "oracle", hashlib.md5(b).hexdigest()[:8]); bad += 1
+        if os.environ.get("FUZZ_DUMP"):     # keep the case for a closer look: <dir>/caseN.npy + .json
+            import json
+            np.save(os.path.join(os.environ["FUZZ_DUMP"], "case%d.npy" % bad), pcm)
+            json.dump(kw, open(os.path.join(os.environ["FUZZ_DUMP"], "case%d.json" % bad), "w"))
     done += 1
 print("oracle vs reference fuzz: %d cases, %d bad" % (done, bad))
 sys.exit(1 if bad else 0)

@@ -6,6 +6,9 @@ import numpy as np
 from hmp3_amd import api, synth
 from oracle import oracle as O
 
+A1 = "--a1" in sys.argv                  # only configurations of the first-generation allocator (dual channel, low-rate joint stereo)
+if A1:
+    sys.argv.remove("--a1")
 SUBMIT = "--submit" in sys.argv          # random-sized calls through hx_batch_submit_s16_device (overlapped) instead of host calls
 if SUBMIT:
     sys.argv.remove("--submit")
@@ -26,11 +29,16 @@ while done < n_cases and tried < 20 * n_cases:
         kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
     else:
         kw["vbr_mnr"] = int(rs.randint(0, 151))
+    if A1:
+        kw.pop("vbr_mnr", None)
+        kw["mode"] = mode = int(rs.choice([1, 2, 2]))
+        kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40] if (mode == 1 or sr < 32000) else [16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
     if rs.rand() < 0.3: kw["hf_flag"] = int(rs.choice([1, 3]))
     if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000, 21000]))
     if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
     if rs.rand() < 0.15: kw["filter_select"] = 1
     if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
+    if rs.rand() < 0.15: kw["nsb_limit"] = int(rs.choice([4, 8, 12, 16, 20, 24, 28, 31]))
     ec = O.default_control(**kw)
     if not O.OracleEncoder(ec).ok():
         continue

@@ -23,6 +23,13 @@ for path in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), r
         per[(r["Dispatch_Id"], name, r["Counter_Name"])] += float(r["Counter_Value"])
     for (d, name, c), v in per.items():
         acc[name][c].append(v)
+# the build the counters belong to: bench.py quotes them only next to the same hx_build_id
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from hmp3_amd import api
+    build_id = api.build_id()
+except Exception:
+    build_id = None
 kern = {}
 for name, cs in acc.items():
     k = {c + ("_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else ""): sum(v) / len(v) for c, v in cs.items()}
@@ -31,8 +38,9 @@ for name, cs in acc.items():
         k["hbm_bytes_corrected"] = (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
     kern[name] = k
 print(json.dumps({
-    "command": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-worst-case --verify 0"
+    "command": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-worst-case --host-fed 0 --verify 0"
                + (" --config %d" % cfg if cfg != 2 else "") + " (one pass per group: sq1, sq2, fetch, write)",
+    "build_id": build_id,
     "workload": {"config": cfg, "streams": S, "frames_per_step": F},
     "units": "FETCH_SIZE / WRITE_SIZE in KB per launch as reported; SQ_* raw counts per launch (cycle counters in quad-cycles); means over the launches of the run",
     "note": "gfx950: hbm_bytes_corrected = 2 * FETCH_SIZE + WRITE_SIZE (16-byte-per-lane streaming loads are tallied at half their bytes; MI355X_MICROARCH.md, HBM section)",
