@@ -462,6 +462,8 @@ def main():
     # status bit 0..2 are failures (hmp3_amd.h); a gate time-out costs overlap only and is counted separately
     mine_bad = (m["status"] != 0) or (m.get("verified", 0) != m.get("verify_n", 0)) or (host_fed is not None and host_fed["kernel_status"] != 0) \
         or (worst is not None and worst["status"] != 0)
+    if os.environ.get("HMP3AMD_BENCH_FAULT_RANK") == str(rank):      # test hook: this rank reports a failure (tests/test_gpu_runtime.py)
+        mine_bad = True
     vals = [m["status"] & 0x7FFFFFFF if m["status"] >= 0 else 0x40000000, m["gate_timeouts"] or 0, m.get("verified", 0), m.get("verify_n", 0), 1 if mine_bad else 0, 1]
     per_rank = [vals]
     k_ms_all = [m["k_ms"]]

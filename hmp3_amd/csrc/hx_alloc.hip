@@ -134,19 +134,21 @@ struct alignas(16) AllocLds {
     int *big_counter;                   // device counter of line passes that took the double table (tests)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
 #ifdef HX_PROFILE
-    unsigned prof[36];                  // 36 slots x 4 bytes keeps the profile build at four workgroups per CU
+    unsigned prof[64];                  // (the profile build holds three workgroups per CU instead of four: per-stream cycles are what it is for)
 #endif
 };
 
 #ifdef HX_PROFILE
 // (only the master wave's time is booked: the helper wave runs some of the same functions)
-#define PROF(id, stmt) do { SYNC(); long long t0_ = clock64(); stmt; SYNC(); if (threadIdx.x == 0 && (id) < 36) L.prof[(id) % 36] += (unsigned) (clock64() - t0_); } while (0)
+#define PROF(id, stmt) do { SYNC(); long long t0_ = clock64(); stmt; SYNC(); if (threadIdx.x == 0 && (id) < 64) L.prof[(id) % 64] += (unsigned) (clock64() - t0_); } while (0)
 #define PROF_T0() long long tp_ = clock64()
-#define PROF_CNT(id) do { if (threadIdx.x == 0 && (id) < 36) L.prof[(id) % 36] += 1; } while (0)
-#define PROF_ACC(id) do { SYNC(); if (threadIdx.x == 0 && (id) < 36) L.prof[(id) % 36] += (unsigned) (clock64() - tp_); tp_ = clock64(); } while (0)
+#define PROF_T1() tp_ = clock64()
+#define PROF_CNT(id) do { if (threadIdx.x == 0 && (id) < 64) L.prof[(id) % 64] += 1; } while (0)
+#define PROF_ACC(id) do { SYNC(); if (threadIdx.x == 0 && (id) < 64) L.prof[(id) % 64] += (unsigned) (clock64() - tp_); tp_ = clock64(); } while (0)
 #else
 #define PROF(id, stmt) do { stmt; } while (0)
 #define PROF_T0() do { } while (0)
+#define PROF_T1() do { } while (0)
 #define PROF_CNT(id) do { } while (0)
 #define PROF_ACC(id) do { } while (0)
 #endif
@@ -497,6 +499,9 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
     SYNC();
     while (__any(mode != 0)) {
         PROF_CNT(20);
+#ifdef HX_PROFILE
+        if (threadIdx.x == 64) L.prof[45] += 1;     // the helper wave's sweeps (channel 1)
+#endif
         const int noise = noise_sweep(L, R, ch, (mode == 0) ? -1 : (mode == 1 ? s : t), sbeg, send, nl);
         if (mode == 1) {
             const int dn = noise - NTarget;
@@ -525,9 +530,11 @@ __device__ void seek_actual(AllocLds &L, const AllocPrm *p)
     const bool two = p->nbmax[1] > 0;
     if (two) HELPER_POST(HCMD_SEEK, 0);
     seek_actual_ch(L, p, 0);
+    PROF_T0();
     if (two) HELPER_JOIN();
     else if (LANE < NB) L.geval[1][LANE] = -1;
     SYNC();
+    PROF_ACC(30);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1164,13 +1171,18 @@ __device__ int quant_count_bits(AllocLds &L, const AllocPrm *p, int opt, int zer
     SYNC();
     PROF_CNT(22);
     const bool two = p->nchan == 2;
+    PROF_T0();
     if (two) HELPER_POST2(HCMD_QUANT_COUNT, opt, ncb[1]);
+    PROF_ACC(42);
     quant_lines(L, p, opt, 0);
     SYNC();
+    PROF_ACC(43);
     if (zero21) { if (LANE == 0) L.ixmax[0][21] = 0; SYNC(); }
     int bits = count_bits_ch(L, p, 0, ncb[0]);
+    PROF_T1();
     if (two) { HELPER_JOIN(); bits += L.hs_bits[1]; }
     SYNC();
+    PROF_ACC(44);
     return bits;
 }
 

@@ -98,8 +98,9 @@ def test_host_entry_points_check_arguments_before_touching_the_device():
         a.Batch(a.default_control(bitrate=64), nstreams=1 << 20, max_frames=64)
 
 
-def _bench(args, timeout=900):
+def _bench(args, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
@@ -111,9 +112,18 @@ def test_bench_two_ranks_encode_disjoint_stream_blocks():
     rc, line, err = _bench(["--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "24", "--frames", "8", "--steps", "2", "--warmup", "1",
                             "--verify", "6", "--no-cpu-baseline", "--no-worst-case"])
     assert rc == 0, (line, err[-2000:])
-    assert line["n_gpus"] == 2 and line["kernel_status"] == 0
-    assert line["verified_streams"] == 6 and line["verify"]["first_mismatch"] is None
+    assert line["n_gpus"] == 2 and line["kernel_status"] == 0 and line["ranks_seen"] == 2 and line["ranks_failed"] == []
+    # every rank checks streams of its own block (6 asked for over two ranks: 3 each)
+    assert line["verified_streams"] == line["verify"]["checked"] == 6 and line["verify"]["first_mismatch"] is None
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
+
+
+def test_bench_line_shows_a_failing_rank_and_exits_non_zero():
+    """a failure on a rank other than 0 must not be invisible: the line names the rank, the exit code is non-zero"""
+    rc, line, err = _bench(["--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "8", "--frames", "4", "--steps", "1", "--warmup", "1",
+                            "--verify", "2", "--no-cpu-baseline", "--no-worst-case", "--host-fed", "0"], extra_env={"HMP3AMD_BENCH_FAULT_RANK": "1"})
+    assert rc != 0 and line is not None
+    assert line["ranks_seen"] == 2 and line["ranks_failed"] == [1]
 
 
 @pytest.mark.parametrize("cfg", [2, 3, 4, 5])
@@ -321,3 +331,34 @@ def test_cli_mnr_adjust_file_switch(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-400:]
     assert b"MNR adjust  10 -200 200 7 0 0" in r.stderr
     assert open(mp3, "rb").read() == open(os.path.join(GOLD, name + ".mp3"), "rb").read()
+
+
+def _ndev():
+    return api().lib().hx_device_count()
+
+
+@pytest.mark.skipif("_ndev() < 2", reason="needs two physical GPUs")
+def test_multi_device_dispatcher_on_two_physical_gpus():
+    """the same dispatcher over two real devices (skipped on a one-GPU box): blocks on device 0 and 1, bytes against the oracle"""
+    a = api()
+    kw = dict(bitrate=64)
+    S, F = 9, 12
+    pcm = np.stack([synth.stream_pcm(4100 + i, F, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    m = a.Multi(a.default_control(**kw), nstreams=S, max_frames=F, devices=[0, 1])
+    assert m.ndevices() == 2 and [m.shard(k)[0] for k in range(2)] == [0, 1]
+    got = m.encode_host(pcm)
+    assert m.status() == 0
+    for s in range(S):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), s
+    m.close()
+
+
+@pytest.mark.skipif("_ndev() < 2", reason="needs two physical GPUs")
+def test_bench_two_ranks_on_two_physical_gpus():
+    """bench.py --gpus 2 as the driver runs it at N = 2: one rank per device over RCCL, every rank verified, health gathered"""
+    rc, line, err = _bench(["--gpus", "2", "--streams", "64", "--frames", "16", "--steps", "3", "--warmup", "1", "--verify", "8",
+                            "--no-cpu-baseline", "--no-worst-case", "--host-fed", "1"])
+    assert rc == 0, (line, err[-2000:])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["ranks_failed"] == [] and line["kernel_status"] == 0
+    assert line["verified_streams"] == line["verify"]["checked"] == 8 and line["host_fed"]["value"] > 0
+    assert len(line["roofline"]["kernel_ms_per_rank"]) == 2
