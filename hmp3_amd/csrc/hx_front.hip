@@ -372,7 +372,8 @@ __device__ __forceinline__ void mdct_kernel(const HxParams *p, const float *pre,
 // values with each neighbour lane.
 
 // (hand-overs inside a wave need no workgroup barrier: its LDS operations execute in order)
-#define FE_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+// (and no s_waitcnt either: a wave's DS instructions are taken in issue order)
+#define FE_WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // The lookup tables every psy / metric step gathers from (mB logarithm, mB exponential): staged in LDS once per
 // workgroup.  Gathers from global memory queue behind the kernel's own streaming loads and stores in the vector
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
     const int btype = bt[unit];
     if (btype == 2) return;
     // (from here on the wave works alone: LDS hand-overs inside a wave need no workgroup barrier)
-#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);
     if (p->alloc1) return;      // the first-generation allocator starts from the raw spectrum
     const int ms = msflag[unit];
