@@ -14,10 +14,17 @@ BUILD_ID=$( (cat *.hip *.inc *.h *.cpp ../build.sh; echo "${HX_OPT:--O3} $HX_EXT
 FLAGS="-DHX_BUILD_ID=\"$BUILD_ID\" --offload-arch=gfx950 ${HX_OPT:--O3} $HX_EXTRA -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
 pids=()
 # hx_front.hip without SLP vectorisation: the packed f32 instructions it forms (v_pk_mul_f32 / v_pk_add_f32) run no faster
-# than the two plain ones on this chip and cost k_spec 300 register moves (measured: k_spec 2.27 -> 2.16 ms)
-for f in hx_front hx_alloc hx_alloc_lsf hx_alloc1 hx_alloc1_lsf hx_pack hx_cabi; do
-  X=""; [ $f = hx_front ] && X="-fno-slp-vectorize"
-  $HIPCC $FLAGS $X -c $f.hip -o $OBJ/$f.o & pids+=($!)
+# than the two plain ones on this chip and cost k_spec 300 register moves (measured: k_spec 2.27 -> 2.16 ms).
+# Scheduling strategy per translation unit, by measurement (ILP = "-mllvm -amdgpu-sched-strategy=iterative-ilp"):
+# the allocator kernels and k_spec / k_prep gain 1 .. 9 %, k_polyphase loses 18 %, k_pack does not care.
+ILP="-mllvm -amdgpu-sched-strategy=iterative-ilp"
+$HIPCC $FLAGS -fno-slp-vectorize -DHX_FRONT_PART=1 -c hx_front.hip -o $OBJ/hx_front1.o & pids+=($!)
+$HIPCC $FLAGS -fno-slp-vectorize $ILP -DHX_FRONT_PART=2 -c hx_front.hip -o $OBJ/hx_front2.o & pids+=($!)
+for f in hx_alloc hx_alloc_lsf hx_alloc1 hx_alloc1_lsf; do
+  $HIPCC $FLAGS $ILP -c $f.hip -o $OBJ/$f.o & pids+=($!)
+done
+for f in hx_pack hx_cabi; do
+  $HIPCC $FLAGS -c $f.hip -o $OBJ/$f.o & pids+=($!)
 done
 for f in hx_host hx_xhead hx_src; do
   g++ -O2 -fPIC -ffp-contract=off -std=c++17 -c $f.cpp -o $OBJ/$f.o & pids+=($!)

@@ -14,8 +14,15 @@
 //   k_carry      K8  roll the 3-granule subband carry and the PCM history
 // Parallel over streams x channels x granules (x slots / subbands / partitions).  Each lane
 // evaluates its unit with the reference's operation order, so results are bit-identical.
+// The file is compiled twice (hmp3_amd/build.sh): HX_FRONT_PART=1 holds k_polyphase and the small kernels, HX_FRONT_PART=2
+// k_spec / k_msscan / k_prep - the latter with LLVM's iterative-ilp scheduling strategy, which suits their long
+// straight-line arithmetic (k_prep 1.50 -> 1.36 ms) and hurts the polyphase loop (1.17 -> 1.38 ms).
 #include "hx_dev.h"
+#ifndef HX_FRONT_PART
+#define HX_FRONT_PART 3     // both
+#endif
 
+#if HX_FRONT_PART & 1
 #define K1_GPB 14                       // granules per workgroup (252 of 256 lanes busy)
 #define K1_NS (480 + 576 * K1_GPB)      // staged samples
 #define K1_LDS (K1_NS + (K1_NS >> 5) + 1)
@@ -292,6 +299,8 @@ __global__ void k_blocktype(HxStream *__restrict__ st, const unsigned char *__re
     }
 }
 
+#endif      // HX_FRONT_PART & 1
+#if HX_FRONT_PART & 2
 // ---- MDCT kernels ------------------------------------------------------------------------------------
 // An N-point kernel (N = 18 for long blocks, 6 for each short window) maps the folded, windowed input f to
 // N spectral lines in three steps:
@@ -942,6 +951,8 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
 #undef WAVE_SYNC
 }
 
+#endif      // HX_FRONT_PART & 2
+#if HX_FRONT_PART & 1
 // After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
 // last 480 input samples into the stream state.
 __global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const int16_t *__restrict__ pcm,
@@ -1013,3 +1024,4 @@ __global__ void k_gate(const unsigned *started_counter, unsigned base, unsigned 
         if (wall_clock64() - t0 > 5000000LL) { atomicAdd(timeouts, 1); break; }
     }
 }
+#endif      // HX_FRONT_PART & 1
