@@ -89,7 +89,8 @@ struct alignas(16) AllocLds {
             int gzero[2][NB], gmin[2][NB], gsf[2][NB], sf[2][NB], active[2][NB];
             int ixmax[2][NB], ix10xmax[2][NB], up[2][NB], lo[2][NB], geval[2][NB], maskmb[2][NB];
             float xsxx[2][NB], x34max[2][NB];
-            float gig[2][NB], gg[2][NB];        // gain pair of the band's current evaluation step
+            float gig[2][NB];                   // 1 / gain^(3/4) of the band's quantiser step
+            alignas(8) float2 gpair[2][NB];     // gain pair (1 / gain^(3/4), gain) of the band's current evaluation step: one read per line
             int lucky[6][2][13];                // big_lucky_noise: noise of candidate c of band (ch, sfb)
         };
         struct {    // first-generation allocator (hx_alloc1.inc): psy model output and noise / mask levels per band in dB
@@ -283,7 +284,7 @@ __device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R, int 
     }
 }
 
-// Noise terms of one channel's lines [lo, nl) for the gain pairs published in L.gig / L.gg.
+// Noise terms of one channel's lines [lo, nl) for the gain pairs published in L.gpair.
 // Chunks of three lines per lane (192 lines per chunk, chunks outside the evaluated range are
 // skipped): per line one gain-pair read, one table read, one store.  All loads of a chunk
 // come before its stores (an LDS store in between would pin the later loads behind it: the
@@ -298,7 +299,8 @@ __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) {
             const int k = 3 * c3 + k3;
-            t[k3] = noise_term_fast(L, L.gig[ch][R.bnd[k]], L.gg[ch][R.bnd[k]], R.x34[k], R.xr[k]);
+            const float2 gp = L.gpair[ch][R.bnd[k]];
+            t[k3] = noise_term_fast(L, gp.x, gp.y, R.x34[k], R.xr[k]);
         }
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
@@ -321,8 +323,9 @@ __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) {
             const int j = LANE + 64 * (3 * c3 + k3), bnd = L.band_of_line[j];
-            const float ig = L.gig[ch][bnd], x34 = L.x34[ch][j];
-            gn[k3] = L.gg[ch][bnd];
+            const float2 gp = L.gpair[ch][bnd];
+            const float ig = gp.x, x34 = L.x34[ch][j];
+            gn[k3] = gp.y;
             xr[k3] = L.xr[ch][j];
             const float tmp = (ig * x34 + (0.0f - 0.0946f));
             qx[k3] = (int) (tmp + copysignf(0.5f, tmp));
@@ -346,18 +349,21 @@ __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl
 __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int ch, int g, int sbeg, int send, int nlines)
 {
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
-    // and the line range that any evaluated band touches
-    int lo = 576, hi = 0;
+    // and the line range that any evaluated band touches: the bands lie in lane order, so it runs from the first
+    // evaluated band's start to the last one's end (two lane reads instead of two wave reductions)
     bool bslow = false;
     PROF_T0();
     if (LANE < NB) {
         const float ig = (g >= 0) ? L.look_34igain[g] : -1.0f;
-        L.gig[ch][LANE] = ig;
-        L.gg[ch][LANE] = (g >= 0) ? L.look_gain[g] : 0.0f;
-        if (g >= 0) { lo = sbeg; hi = send; bslow = noise_band_needs_pow(ig, L.x34max[ch][LANE]); }
+        L.gpair[ch][LANE] = make_float2(ig, (g >= 0) ? L.look_gain[g] : 0.0f);
+        if (g >= 0) bslow = noise_band_needs_pow(ig, L.x34max[ch][LANE]);
     }
-    lo = -hx_wave_max(-lo);
-    hi = hx_wave_max(hi);
+    const unsigned long long evald = __ballot(LANE < NB && g >= 0);
+    int lo = 576, hi = 0;
+    if (evald) {
+        lo = __builtin_amdgcn_readlane(sbeg, __builtin_ctzll(evald));
+        hi = __builtin_amdgcn_readlane(send, 63 - __builtin_clzll(evald));
+    }
     SYNC();
     PROF_ACC(27);
     const int nl = min(nlines, hi);

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
-bash tools/kprof.sh cur new 2>&1 | grep -E "==|k_alloc|k_spec|k_prep|k_poly|k_pack "
-AB_ROUNDS=2 bash tools/ab.sh cur new
-AB_ROUNDS=1 AB_ARGS="--config 3 --steps 6 --warmup 1" bash tools/ab.sh cur new
