@@ -354,8 +354,10 @@ int encode_streaming(const char *fin, const char *fout, const Options &opt)
         }
         in.audio_bytes = audio;
         if (in.ec_used.samprate < 32000) frames_expected *= 2;                          // MPEG-2: two frames per call (tomp3.cpp:1022)
-        while (!werr && hx_enc_get_frames(enc) < frames_expected)                       // drain, tomp3.cpp:1020-1036
+        // drain, tomp3.cpp:1020-1036 (bounded: an encoder that stopped emitting - a failed device call - must not hang the tool)
+        for (unsigned spare = frames_expected + 64; !werr && hx_enc_get_frames(enc) < frames_expected && spare; spare--)
             emit(hx_enc_MP3_audio_encode(enc, zero.data(), bs.data()));
+        if (hx_enc_get_frames(enc) < frames_expected) { fprintf(stderr, "\n ENCODER FAIL: %s\n", hx_last_error()); break; }
         if (werr) { fprintf(stderr, "\n FILE WRITE ERROR\n"); break; }
         const unsigned frames = hx_enc_get_frames(enc);
         if (opt.xing_flag) {

@@ -29,7 +29,7 @@ while done < n_cases and tried < 30 * n_cases:
     if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
     if rs.rand() < 0.15: kw["filter_select"] = 1
     if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
-    if rs.rand() < 0.15: kw["nsb_limit"] = int(rs.choice([4, 8, 12, 16, 20, 24, 28, 31]))
+    if rs.rand() < 0.15: kw["nsb_limit"] = int(rs.choice([2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 31]))
     ok_o = O.OracleEncoder(O.default_control(**kw)).ok()
     r = O.RefEncoder(O.default_control(**kw))
     ok_r = r.bytes_in > 0
