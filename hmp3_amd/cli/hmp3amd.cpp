@@ -310,7 +310,13 @@ int encode_streaming(const char *fin, const char *fout, const Options &opt)
         const size_t slack = 1 << 17, piece = 1 << 20;
         std::vector<unsigned char> win(piece + (size_t) init_bytes + slack, 0), bs(128 * 1024), zero((size_t) 4 * init_bytes + slack, 0);
         size_t lo = 0, hi = 0;                  // valid bytes of the window: [lo, hi)
-        uint64_t audio = 0, zeros_left = 4ull * (uint64_t) init_bytes;
+        // The reference appends the four calls' worth of silence only if it fits a limit derived from its input buffer
+        // (128 frames of stereo floats) and a per-format factor (tomp3.cpp:268,802,925; pcmhpm.c:450): with 32-bit
+        // samples and a down-conversion by more than 1.14 (24-bit: 2.03) it never does, and the tail of the input that
+        // is shorter than one call's need is dropped.  Found by tools/fuzz_cli.py.
+        const uint64_t ref_bufbytes = 128ull * sizeof(float) * 2304, fmt_factor = (uint64_t) in.wi.channels * (uint64_t) ((in.wi.bits * 7) / 8);
+        const bool pad_fits = fmt_factor != 0 && (((ref_bufbytes << 1) / fmt_factor) & ~1ull) > 4ull * (uint64_t) init_bytes;
+        uint64_t audio = 0, zeros_left = pad_fits ? 4ull * (uint64_t) init_bytes : 0;
         bool eof = false, werr = false;
         unsigned frames_expected = 0;
         auto emit = [&](const HX_IN_OUT &x) {

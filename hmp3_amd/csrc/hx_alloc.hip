@@ -824,7 +824,7 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
         L.gsf[ch][i] = max(GG - smin, 0);
     }
     // The work list lived in channel 0's line buffer (at most 6 x 26 entries).  The quantiser rewrites the coded lines
-    // only: with a very low subband limit (-C4 at 48 kHz: 72 lines) the list's tail would stay behind as lines
+    // only: with a very low subband limit (E_CONTROL.nsb_limit = 4 at 48 kHz: 72 lines) the list's tail would stay behind as lines
     // (found by the round-3 sweep with nsb_limit in the draw).  Lines past the coded range are zero by contract.
     for (int j = p->nbmax[0] + LANE; j < 6 * 26; j += 64) L.ix[0][j] = 0;
     SYNC();

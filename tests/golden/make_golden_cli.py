@@ -49,6 +49,12 @@ CASES = {
     "cli_src_48k_to_24k_s24": (923, 40001, 48000, 24, True, ["-A2", "-B32"]),             # 2:1 down, one filter bank
     "cli_src_44k_to_32k_s16": (924, 40003, 44100, False, True, ["-A32000", "-B64"]),      # 441:320 down, two stages
     "cli_src_44k_to_22k_downmix": (925, 40007, 44100, False, False, ["-A22050", "-M3", "-V50"]),   # down + down-mix
+    # the reference appends its four calls' worth of silence only if that fits a limit that depends on the sample format
+    # (tomp3.cpp:925): 32-bit samples converted down by more than 1.14, or 24-bit by more than 2.03, never get it, and the
+    # tail of the input that is shorter than one call's need is dropped
+    "cli_src_44k_to_16k_f32_nopad": (932, 20011, 44100, True, True, ["-A16000", "-B32"]),
+    "cli_src_48k_to_22k_s24_nopad": (933, 30011, 48000, 24, False, ["-A22050", "-V60"]),
+    "cli_src_24k_to_22k_s32_nopad": (934, 14301, 24000, 32, True, ["-A22050", "-B128", "-M1", "-N16"]),
     # the reference's first-generation allocator: intensity stereo (MPEG-2 below 48 kbps total; MPEG-1 on request, -N), dual channel (-M2)
     "cli_is_lsf_cbr32_s16_22k": (926, 50003, 22050, False, True, ["-B16"]),
     "cli_is_lsf_cbr16_f32_16k": (927, 40001, 16000, True, False, ["-B8"]),

@@ -86,6 +86,7 @@ def test_batch_bitstream_byte_identical_to_oracle(name):
                                   "cli_ext_vbr60_s24_48k", "cli_odd_cbr64_u8_mono_44k",
                                   "cli_src_11k_to_22k_s16", "cli_src_8k_to_16k_u8_mono", "cli_src_32k_to_44k_f32",
                                   "cli_src_48k_to_24k_s24", "cli_src_44k_to_32k_s16", "cli_src_44k_to_22k_downmix",
+                                  "cli_src_44k_to_16k_f32_nopad", "cli_src_48k_to_22k_s24_nopad", "cli_src_24k_to_22k_s32_nopad",
                                   "cli_is_lsf_cbr32_s16_22k", "cli_is_lsf_cbr16_f32_16k", "cli_is_n8_cbr128_s16_44k",
                                   "cli_dual_cbr128_s24_44k", "cli_dual_lsf_cbr48_s16_24k"])
 def test_cli_whole_file_byte_identical_to_reference_cli(name, tmp_path):
@@ -463,7 +464,7 @@ def random_control(rng):
     if rng.random() < 0.15:
         kw["quick"] = 1
     if rng.random() < 0.2:
-        kw["nsb_limit"] = int(rng.choice([2, 4, 6, 10, 14, 18, 22, 26, 30]))      # -C: subband limit set by the user
+        kw["nsb_limit"] = int(rng.choice([2, 4, 6, 10, 14, 18, 22, 26, 30]))      # subband limit set by the caller
     return kw
 
 
@@ -499,7 +500,7 @@ def test_random_configurations_against_the_oracle():
                                 dict(samprate=44100, bitrate=160, nsb_limit=2), dict(samprate=32000, vbr_mnr=120, nsb_limit=3)],
                          ids=["48k_c4", "48k_c4_hf", "44k_c2", "32k_c3"])
 def test_very_low_subband_limits(kw):
-    """-C with a handful of subbands (72 lines or fewer are coded): the scalefactor refinement's work list shares the
+    """E_CONTROL.nsb_limit of a handful of subbands (72 lines or fewer are coded): the scalefactor refinement's work list shares the
     line buffer, and lines past the coded range must still come out zero (found by the round-3 sweep, 3 cases in 2500)"""
     S, F = 6, 12
     pcm = np.stack([synth.stream_pcm(656405 + i, F, sr=kw["samprate"], rho=[1.0, 0.7, 0.0, 0.3][i % 4], bursts=(i % 2 == 0)) for i in range(S)])

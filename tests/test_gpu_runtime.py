@@ -362,3 +362,12 @@ def test_bench_two_ranks_on_two_physical_gpus():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["ranks_failed"] == [] and line["kernel_status"] == 0
     assert line["verified_streams"] == line["verify"]["checked"] == 8 and line["host_fed"]["value"] > 0
     assert len(line["roofline"]["kernel_ms_per_rank"]) == 2
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hmp3")), reason="oracle/_ref/hmp3 (the reference's CLI, prebuilt) not present")
+def test_fuzz_cli_slice_against_the_reference_binary():
+    """a slice of tools/fuzz_cli.py: random WAVs (rates incl. the converter's, sample formats, containers) x random flags,
+    hmp3amd against the reference's own command line, whole files.  (The sweep found the reference's conditional
+    end-of-input padding: 32-bit samples converted down by more than 1.14 never get the four calls of silence.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "60", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]

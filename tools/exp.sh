@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x 2>&1 | tail -4
-python tools/fuzz_parity.py 600 41001 2>&1 | tail -3
-python tools/fuzz_parity.py --submit 400 41002 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py -q -x -k "cli_whole_file or reference_cli_source" 2>&1 | tail -4
+python tools/fuzz_cli.py 400 2 2>&1 | tail -30

@@ -1,0 +1,73 @@
+"""Randomised whole-file sweep of the command line: random WAV (rate incl. the ones that need the rate converter, mono /
+stereo, 8 / 16 / 24 / 32-bit or float samples, RIFF / RIFX / RF64 / Wave64 / extensible header) x random flags,
+hmp3_amd/hmp3amd (GPU) against the real reference's CLI (oracle/_ref/hmp3, the prebuilt binary), file for file.
+python tools/fuzz_cli.py [n_cases] [seed]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import numpy as np                      # noqa: E402
+import make_golden_cli as M             # noqa: E402
+from hmp3_amd import synth              # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "hmp3")
+CLI = os.path.join(ROOT, "hmp3_amd", "hmp3amd")
+assert os.path.exists(REF), "oracle/_ref/hmp3 missing (make -C oracle ref)"
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
+bad = done = 0
+with tempfile.TemporaryDirectory() as d:
+    wav, a, b = os.path.join(d, "in.wav"), os.path.join(d, "ref.mp3"), os.path.join(d, "gpu.mp3")
+    while done < n_cases:
+        sr = int(rs.choice([8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000]))
+        mono = rs.rand() < 0.3
+        fmt = [False, True, 8, 24, 32][int(rs.randint(0, 5))]          # 16-bit, float, 8 / 24 / 32-bit integer
+        container = None
+        if fmt in (False, 24) and rs.rand() < 0.4:
+            container = str(rs.choice(["rifx", "rf64", "w64", "ext"]))
+        if mono and fmt in (24, 32):
+            fmt = False                 # (the WAV writer's mono branch knows 8 / 16-bit and float)
+        if mono:
+            container = None
+        nsamp = int(rs.randint(3000, 50000))
+        nfr = (nsamp + 1151) // 1152
+        pcm = synth.stream_pcm(int(rs.randint(0, 1 << 20)), nfr, sr=sr, rho=float(rs.choice([0.0, 0.5, 1.0])), bursts=bool(rs.rand() < 0.5))[:nsamp]
+        if mono:
+            pcm = pcm[:, 0].copy()
+        flags = []
+        if rs.rand() < 0.5: flags.append("-B%d" % int(rs.choice([8, 16, 24, 32, 48, 64, 96, 128, 160])))
+        else: flags.append("-V%d" % int(rs.randint(0, 151)))
+        if rs.rand() < 0.5: flags.append("-M%d" % int(rs.choice([0, 1, 2, 3])))
+        if rs.rand() < 0.3: flags.append("-HF%d" % int(rs.choice([0, 2])))
+        if rs.rand() < 0.3: flags.append("-F%d" % int(rs.choice([6000, 12000, 16000, 19000, 22000])))
+        if rs.rand() < 0.3: flags.append("-SBT%d" % int(rs.choice([0, 300, 700, 2000, 99999])))
+        if rs.rand() < 0.2: flags.append("-S1")
+        if rs.rand() < 0.3: flags.append("-X%d" % int(rs.choice([0, 1, 2])))
+        if rs.rand() < 0.2: flags.append("-A%d" % int(rs.choice([0, 1, 2, 16000, 22050, 24000, 32000, 44100, 48000])))
+        if rs.rand() < 0.15: flags.append("-N%d" % int(rs.choice([4, 8, 12, 16])))
+        if rs.rand() < 0.15: flags.append("-C%d" % int(rs.choice([0, 1])))
+        if rs.rand() < 0.15: flags.append("-T%d" % int(rs.randint(-40, 51)))
+        if rs.rand() < 0.15: flags.append("-L%d" % int(rs.choice([64, 96, 128, 160])))
+        M.write_wav(wav, pcm, sr, fmt, container)
+        for f in (a, b):
+            if os.path.exists(f):
+                os.remove(f)
+        r1 = subprocess.run([REF, wav, a] + flags, capture_output=True)
+        r2 = subprocess.run([CLI, wav, b] + flags, capture_output=True)
+        ok1, ok2 = os.path.exists(a) and os.path.getsize(a) > 0, os.path.exists(b) and os.path.getsize(b) > 0
+        if not ok1 and not ok2:
+            continue                    # both reject the combination: not a case
+        done += 1
+        same = ok1 and ok2 and open(a, "rb").read() == open(b, "rb").read()
+        if not same:
+            bad += 1
+            print("MISMATCH sr %d mono %s fmt %s container %s nsamp %d flags %s | reference %s bytes rc %d, gpu %s bytes rc %d" % (
+                sr, mono, fmt, container, nsamp, " ".join(flags), os.path.getsize(a) if ok1 else None, r1.returncode,
+                os.path.getsize(b) if ok2 else None, r2.returncode))
+            print("   ", r2.stderr.decode()[-200:].replace("\\n", " | "))
+print("cli fuzz: %d cases, %d bad" % (done, bad))
+sys.exit(1 if bad else 0)

@@ -23,6 +23,12 @@ while done < n_batches:
         if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000]))
         if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 99999]))
         if rs.rand() < 0.1: kw["filter_select"] = 1
+        if rs.rand() < 0.1: kw["nsb_limit"] = int(rs.choice([2, 3, 4, 6, 8, 12, 16, 24, 31]))
+        if rs.rand() < 0.15: kw["vbr_delta_mnr"] = int(rs.randint(-60, 71))
+        if rs.rand() < 0.15: kw["test1"] = int(rs.randint(0, 16))
+        if rs.rand() < 0.1: kw["quick"] = int(rs.choice([0, 1]))
+        if rs.rand() < 0.1: kw["freq_limit"] = int(rs.randint(500, 24001))
+        if rs.rand() < 0.1: kw["short_block_threshold"] = int(rs.randint(0, 3001))
         e = O.OracleEncoder(O.default_control(**kw))
         if not e.ok(): continue
         kws.append(kw)

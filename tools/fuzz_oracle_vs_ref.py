@@ -30,6 +30,15 @@ while done < n_cases and tried < 30 * n_cases:
     if rs.rand() < 0.15: kw["filter_select"] = 1
     if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
     if rs.rand() < 0.15: kw["nsb_limit"] = int(rs.choice([2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 31]))
+    # the remaining knobs of E_CONTROL (pub/encapp.h:42-72): VBR bitrate cap and MNR offset, tuning switches, header bits,
+    # arbitrary cut-offs and block-switching thresholds
+    if rs.rand() < 0.2: kw["vbr_br_limit"] = int(rs.choice([16, 32, 48, 64, 96, 128, 160]))
+    if rs.rand() < 0.2: kw["vbr_delta_mnr"] = int(rs.randint(-60, 71))
+    if rs.rand() < 0.2: kw["test1"] = int(rs.randint(0, 16))
+    if rs.rand() < 0.15: kw["quick"] = int(rs.choice([0, 1]))
+    if rs.rand() < 0.1: kw["cr_bit"] = int(rs.randint(0, 2)); kw["original"] = int(rs.randint(0, 2))
+    if rs.rand() < 0.15: kw["freq_limit"] = int(rs.randint(500, 24001))
+    if rs.rand() < 0.15: kw["short_block_threshold"] = int(rs.randint(0, 3001))
     ok_o = O.OracleEncoder(O.default_control(**kw)).ok()
     r = O.RefEncoder(O.default_control(**kw))
     ok_r = r.bytes_in > 0
@@ -55,8 +64,15 @@ while done < n_cases and tried < 30 * n_cases:
     elif kind == 6: pcm[:, 1] = -pcm[:, 0]
     if kw["mode"] == 3:
         pcm = np.ascontiguousarray(pcm[:, 0])
-    a = O.encode_stream(r, pcm)
-    b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+    if rs.rand() < 0.25:        # the fp32 entry point (L3_audio_encode), fractional sample values
+        pcmf = (pcm.astype(np.float32) + rs.uniform(-0.5, 0.5, size=pcm.shape).astype(np.float32)).astype(np.float32)
+        rf, of = O.RefEncoder(O.default_control(**kw), s16=False), O.OracleEncoder(O.default_control(**kw))
+        a = b"".join(rf.encode_f32(pcmf[f * 1152:(f + 1) * 1152]) for f in range(F))
+        b = b"".join(of.encode_f32(pcmf[f * 1152:(f + 1) * 1152]) for f in range(F))
+        sig["f32"] = True
+    else:
+        a = O.encode_stream(r, pcm)
+        b = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
     if a != b:
         import hashlib
         print("MISMATCH", kw, len(a), len(b), "F", F, sig, "md5 reference", hashlib.md5(a).hexdigest()[:8], "oracle", hashlib.md5(b).hexdigest()[:8]); bad += 1

@@ -39,11 +39,20 @@ while done < n_cases and tried < 20 * n_cases:
     if rs.rand() < 0.15: kw["filter_select"] = 1
     if rs.rand() < 0.15: kw["nsbstereo"] = int(rs.choice([4, 8, 12, 16]))
     if rs.rand() < 0.15: kw["nsb_limit"] = int(rs.choice([2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 31]))
+    # the remaining knobs of E_CONTROL (pub/encapp.h:42-72): VBR bitrate cap and MNR offset, tuning switches, header bits,
+    # arbitrary cut-offs and block-switching thresholds
+    if rs.rand() < 0.2: kw["vbr_br_limit"] = int(rs.choice([16, 32, 48, 64, 96, 128, 160]))
+    if rs.rand() < 0.2: kw["vbr_delta_mnr"] = int(rs.randint(-60, 71))
+    if rs.rand() < 0.2: kw["test1"] = int(rs.randint(0, 16))
+    if rs.rand() < 0.15: kw["quick"] = int(rs.choice([0, 1]))
+    if rs.rand() < 0.1: kw["cr_bit"] = int(rs.randint(0, 2)); kw["original"] = int(rs.randint(0, 2))
+    if rs.rand() < 0.15: kw["freq_limit"] = int(rs.randint(500, 24001))
+    if rs.rand() < 0.15: kw["short_block_threshold"] = int(rs.randint(0, 3001))
     ec = O.default_control(**kw)
     if not O.OracleEncoder(ec).ok():
         continue
     nch = 1 if mode == 3 else 2
-    S, F = 6, int(rs.choice([7, 12, 20]))
+    S, F = 6, int(rs.choice([7, 12, 20, 20, 20, 120]))     # (now and then a long run: reservoir wrap, padding cycle, VBR pool limiter)
     seeds = rs.randint(0, 1 << 20, size=S)
     rhos = rs.choice([0.0, 0.3, 0.7, 1.0], size=S)
     amp = rs.choice([1.0, 1.0, 0.25, 0.02], size=S)
@@ -61,6 +70,10 @@ while done < n_cases and tried < 20 * n_cases:
     elif kind == 6: pcm[0, :, 1] = -pcm[0, :, 0]        # anti-phase channels
     if nch == 1:
         pcm = np.ascontiguousarray(pcm[:, :, 0])
+    # a quarter of the cases through the fp32 entry points, with fractional sample values (host-call mode)
+    as_f32 = (not SUBMIT) and rs.rand() < 0.25
+    if as_f32:
+        pcm = (pcm.astype(np.float32) + rs.uniform(-0.5, 0.5, size=pcm.shape).astype(np.float32)).astype(np.float32)
     try:
         b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
     except Exception as e:
@@ -96,9 +109,9 @@ while done < n_cases and tried < 20 * n_cases:
     b.close()
     for s in range(S):
         enc = O.OracleEncoder(O.default_control(**kw))
-        want = b"".join(enc.encode_s16(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F))
+        want = b"".join((enc.encode_f32 if as_f32 else enc.encode_s16)(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F))
         if got[s] != want or st != 0:
-            print("MISMATCH", kw, "stream", s, "seed", int(seeds[s]), "rho", float(rhos[s]), "amp", float(amp[s]), "status", st, len(got[s]), len(want))
+            print("MISMATCH", kw, "stream", s, "seed", int(seeds[s]), "rho", float(rhos[s]), "amp", float(amp[s]), "status", st, len(got[s]), len(want), "f32" if as_f32 else "s16", "F", F)
             bad += 1
             break
     done += 1
