@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build the MI355X encoder library in-tree: hmp3_amd/libhmp3amd.so (gfx950 only).
 # -ffp-contract=off: the kernels must not fuse multiply-adds (bit-exactness against the oracle).
-# HX_EXTRA: extra compiler flags (e.g. -DHX_PROFILE); HX_LIBNAME: build a variant library next to the product
+# HX_EXTRA: extra compiler flags (e.g. -DHX_PROFILE); HX_ALLOC_EXTRA: the same for the allocator kernels only; HX_LIBNAME: build a variant library next to the product
 # (objects go to a directory of their own, so variants can be built side by side).
 set -e
 cd "$(dirname "$0")/csrc"
@@ -10,18 +10,19 @@ LIB=${HX_LIBNAME:-libhmp3amd.so}
 OBJ=$(mktemp -d /tmp/hxbuild.XXXXXX)
 trap 'rm -rf "$OBJ"' EXIT
 # build id = hash of the kernel / host sources and of the flags that change the generated code
-BUILD_ID=$( (cat *.hip *.inc *.h *.cpp ../build.sh; echo "${HX_OPT:--O3} $HX_EXTRA") | sha256sum | cut -c1-16)
+BUILD_ID=$( (cat *.hip *.inc *.h *.cpp ../build.sh; echo "${HX_OPT:--O3} $HX_EXTRA ${HX_ALLOC_OPT:--O2} $HX_ALLOC_EXTRA") | sha256sum | cut -c1-16)
 FLAGS="-DHX_BUILD_ID=\"$BUILD_ID\" --offload-arch=gfx950 ${HX_OPT:--O3} $HX_EXTRA -fPIC -ffp-contract=off -fno-fast-math -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable -Wno-unused-value -Wno-unused-result"
 pids=()
 # hx_front.hip without SLP vectorisation: the packed f32 instructions it forms (v_pk_mul_f32 / v_pk_add_f32) run no faster
 # than the two plain ones on this chip and cost k_spec 300 register moves (measured: k_spec 2.27 -> 2.16 ms).
 # Scheduling strategy per translation unit, by measurement (ILP = "-mllvm -amdgpu-sched-strategy=iterative-ilp"):
-# the allocator kernels and k_spec / k_prep gain 1 .. 9 %, k_polyphase loses 18 %, k_pack does not care.
+# the allocator kernels and k_spec / k_prep gain 1 .. 9 %, k_polyphase loses 18 %, k_pack does not care.  The allocator
+# kernels are built at -O2: -O3 is 1 % slower there (measured twice, alternating builds), -Os 2.5 %.
 ILP="-mllvm -amdgpu-sched-strategy=iterative-ilp"
 $HIPCC $FLAGS -fno-slp-vectorize -DHX_FRONT_PART=1 -c hx_front.hip -o $OBJ/hx_front1.o & pids+=($!)
 $HIPCC $FLAGS -fno-slp-vectorize $ILP -DHX_FRONT_PART=2 -c hx_front.hip -o $OBJ/hx_front2.o & pids+=($!)
 for f in hx_alloc hx_alloc_lsf hx_alloc1 hx_alloc1_lsf; do
-  $HIPCC $FLAGS $ILP -c $f.hip -o $OBJ/$f.o & pids+=($!)
+  $HIPCC $FLAGS $ILP ${HX_ALLOC_OPT:--O2} $HX_ALLOC_EXTRA -c $f.hip -o $OBJ/$f.o & pids+=($!)
 done
 for f in hx_pack hx_cabi; do
   $HIPCC $FLAGS -c $f.hip -o $OBJ/$f.o & pids+=($!)
