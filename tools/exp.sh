@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-AB_ROUNDS=2 AB_VERIFY=4 bash tools/ab.sh cur f6 g1 g2 g3
-bash tools/kprof.sh cur g1 2>&1 | grep -E "==|k_alloc|k_spec|k_prep|k_poly|k_pack "
+mkdir -p gpurun_out/profiles_r03
+for c in 2 3 4 5; do python3 bench.py --config $c 2>/dev/null | tail -1 > gpurun_out/profiles_r03/r03_bench_line_config$c.json; done
