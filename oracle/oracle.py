@@ -38,6 +38,7 @@ def _load(path):
 
 _lib = None
 _ref = None
+_ref_zero = None
 
 
 def lib():
@@ -81,6 +82,21 @@ def ref():
             _ref.ref_mbExp.argtypes = [C.c_int]
             _ref.ref_mbExp.restype = C.c_float
     return _ref
+
+
+def ref_zero():
+    """the reference compiled with every uninitialised local defined as zero (make -C oracle ref_zero), or None"""
+    global _ref_zero
+    if _ref_zero is None:
+        _ref_zero = _load(os.path.join(HERE, "_ref", "libhmp3ref_zero.so"))
+        if _ref_zero is not None:
+            _ref_zero.ref_new.restype = C.c_void_p
+            _ref_zero.ref_free.argtypes = [C.c_void_p]
+            _ref_zero.ref_init.argtypes = [C.c_void_p, C.POINTER(Control)]
+            _ref_zero.ref_init_s16.argtypes = [C.c_void_p, C.POINTER(Control)]
+            _ref_zero.ref_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            _ref_zero.ref_encode_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    return _ref_zero
 
 
 class RefDump(C.Structure):
@@ -137,8 +153,8 @@ class OracleEncoder:
 class RefEncoder:
     """one stream through the real reference (None-safe: check oracle.ref() first)"""
 
-    def __init__(self, ec, s16=True):
-        self.r = ref()
+    def __init__(self, ec, s16=True, zero_locals=False):
+        self.r = ref_zero() if zero_locals else ref()
         self.h = self.r.ref_new()
         self.s16 = s16
         self.bytes_in = (self.r.ref_init_s16 if s16 else self.r.ref_init)(self.h, C.byref(ec))

@@ -31,20 +31,30 @@ STREAM_CASES = {
     "vbr50_default_bursts": (dict(), 44100, 40, 0.7, True),
 }
 
-# streams whose signal is more than a seed: name -> (E_CONTROL overrides, sample rate, frames, seed, rho, bursts, amplitude, right = -left)
+# streams whose signal is more than a seed: name -> (E_CONTROL overrides, sample rate, frames, seed, rho, bursts, amplitude,
+# right = -left[, DC offset added after scaling, reference build with zeroed locals])
 # a1_dual_16k_antiphase: dual channel at 2 x 8 kbps, the first-generation allocator; with the double-precision log10 the
 # reference does NOT use there (bitallo1.cpp is C++: log10f) an encoder codes one more line in the second frame
+# stab_odd_npart_32k: the reference's spd_smrLongEcho (spdsmr.c) reads stab[npart], a local it never wrote, when the psy
+# model's partition count is odd; after short-block frames the slot holds stack residue and the reference's own output
+# depends on it (1 case in 90 000 of tools/fuzz_oracle_vs_ref.py).  The oracle and the GPU define the slot as 0; the golden
+# bytes come from the reference compiled with -ftrivial-auto-var-init=zero (make -C oracle ref_zero), which is the same
+# code with that read defined.
 EXTRA_CASES = {
     "a1_dual_16k_antiphase": (dict(samprate=16000, mode=2, bitrate=8), 16000, 40, 181220, 1.0, True, 0.25, True),
+    "stab_odd_npart_32k": (dict(samprate=32000, mode=0, vbr_mnr=66, hf_flag=3, freq_limit=5407, short_block_threshold=700,
+                                vbr_br_limit=32, vbr_delta_mnr=58), 32000, 40, 411809, 0.0, True, 0.02, False, -19984, True),
 }
 
 
 def extra_case_pcm(name):
-    kw, sr, nfr, seed, rho, bursts, amp, anti = EXTRA_CASES[name]
+    kw, sr, nfr, seed, rho, bursts, amp, anti = EXTRA_CASES[name][:8]
     pcm = synth.stream_pcm(seed, nfr, sr=sr, rho=rho, bursts=bursts)
     pcm = (pcm.astype(np.float64) * amp).astype(np.int16)
     if anti:
         pcm[:, 1] = -pcm[:, 0]
+    if len(EXTRA_CASES[name]) > 8:
+        pcm = np.clip(pcm.astype(np.int32) + EXTRA_CASES[name][8], -32768, 32767).astype(np.int16)
     return pcm
 
 
@@ -133,8 +143,12 @@ def main():
                                         initialMNR=d.initialMNR, nsf=list(d.nsf)),
                           state=state)
         print("%-26s %6d bytes, %d frames" % (name, sum(sizes), nfr))
-    for name, (kw, sr, nfr, seed, rho, bursts, amp, anti) in EXTRA_CASES.items():
-        data = O.encode_stream(O.RefEncoder(O.default_control(**kw)), extra_case_pcm(name))
+    for name, case in EXTRA_CASES.items():
+        kw, nfr = case[0], case[2]
+        zero_locals = len(case) > 9 and case[9]
+        if zero_locals and O.ref_zero() is None:
+            raise SystemExit("oracle/_ref/libhmp3ref_zero.so missing: run `make -C oracle ref_zero` first")
+        data = O.encode_stream(O.RefEncoder(O.default_control(**kw), zero_locals=zero_locals), extra_case_pcm(name))
         with open(os.path.join(GOLD, name + ".mp3frames"), "wb") as fh:
             fh.write(data)
         print("%-26s %6d bytes, %d frames" % (name, len(data), nfr))

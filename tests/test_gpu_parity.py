@@ -594,10 +594,11 @@ def test_golden_reference_streams(name):
     b.close()
 
 
-@pytest.mark.parametrize("name", ["a1_dual_16k_antiphase"])
+@pytest.mark.parametrize("name", ["a1_dual_16k_antiphase", "stab_odd_npart_32k"])
 def test_extra_golden_reference_streams(name):
     """committed reference bitstreams of make_golden.EXTRA_CASES (signals that are more than a seed): the dual-channel
-    stream of the first-generation allocator that tells libm's log10f / logf (hx_libm32.h) from the double functions"""
+    stream of the first-generation allocator that tells libm's log10f / logf (hx_libm32.h) from the double functions; the
+    32 kHz stream on which the reference's psy model reads a local it never wrote (golden from the zeroed-locals build)"""
     sys.path.insert(0, GOLD)
     import make_golden as M
     kw, nfr = M.EXTRA_CASES[name][0], M.EXTRA_CASES[name][2]

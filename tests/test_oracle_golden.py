@@ -130,10 +130,11 @@ def _extra():
     return M
 
 
-@pytest.mark.parametrize("name", ["a1_dual_16k_antiphase"])
+@pytest.mark.parametrize("name", ["a1_dual_16k_antiphase", "stab_odd_npart_32k"])
 def test_extra_golden_streams(name):
     """streams whose signal is more than a seed (make_golden.EXTRA_CASES): the first-generation allocator's dual-channel
-    case that separates libm's log10f (what the reference's C++ calls) from the double log10"""
+    case that separates libm's log10f (what the reference's C++ calls) from the double log10; the 32 kHz VBR stream on which
+    spd_smrLongEcho reads stab[npart] unwritten (golden = reference built with -ftrivial-auto-var-init=zero)"""
     M = _extra()
     kw = M.EXTRA_CASES[name][0]
     got = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), M.extra_case_pcm(name))

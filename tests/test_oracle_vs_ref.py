@@ -312,3 +312,24 @@ def test_first_generation_allocator_random_controls_byte_identical():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_vs_ref.py"), "--a1", "150", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+@pytest.mark.skipif(O.ref_zero() is None, reason="oracle/_ref/libhmp3ref_zero.so not built (make -C oracle ref_zero)")
+def test_uninitialised_psy_local_is_defined_as_zero():
+    """spdsmr.c spd_smrLongEcho reads stab[i + 1] with i + 1 == npart, a slot nothing wrote, when npart is odd (32 kHz
+    long blocks).  Its value is stack residue: usually harmless, after short-block frames it can move a mask.  The oracle
+    (and the GPU) read 0 there; the reference compiled with clang -ftrivial-auto-var-init=zero is the same encoder with
+    that read defined, and the oracle must equal it on the stream where the gcc build's residue changes the output."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as M
+    name = "stab_odd_npart_32k"
+    kw = M.EXTRA_CASES[name][0]
+    pcm = M.extra_case_pcm(name)
+    z = O.encode_stream(O.RefEncoder(O.default_control(**kw), zero_locals=True), pcm)
+    o = O.encode_stream(O.OracleEncoder(O.default_control(**kw)), pcm)
+    assert z == o
+    # ... and on ordinary material the zeroed-locals build is the reference, byte for byte
+    kw2 = dict(samprate=44100, vbr_mnr=50)
+    pcm2 = synth.stream_pcm(7, 24, sr=44100, rho=0.7, bursts=True)
+    assert O.encode_stream(O.RefEncoder(O.default_control(**kw2), zero_locals=True), pcm2) == \
+        O.encode_stream(O.RefEncoder(O.default_control(**kw2)), pcm2)
