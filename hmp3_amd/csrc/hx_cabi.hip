@@ -14,6 +14,7 @@
 
 // kernels (hx_front.hip / hx_alloc.hip)
 #define K1_GPB 14
+#define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
                             const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan, int *eng, int lsf);
 __global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S, int nchan);
@@ -558,7 +559,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     // (the carry in slots 0..2 is not written by k_polyphase, so the two may run in either order)
     int tot = S * 2 * 9;
     LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot, b->lsf);
-    LAUNCH(k_polyphase, g1, dim3(512), q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan, b->d_eng, b->lsf);
+    LAUNCH(k_polyphase, g1, dim3(K1_THREADS), q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan, b->d_eng, b->lsf);
     tot = S * NG;
     LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
            b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);

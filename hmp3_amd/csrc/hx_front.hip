@@ -24,6 +24,8 @@
 
 #if HX_FRONT_PART & 1
 #define K1_GPB 14                       // granules per workgroup (252 of 256 lanes busy)
+#define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
+
 #define K1_NS (480 + 576 * K1_GPB)      // staged samples
 #define K1_LDS (K1_NS + (K1_NS >> 5) + 1)
 
@@ -34,10 +36,11 @@
 // resolved at compile time into straight-line code, depth first.  Each sum is one rounding, in the order
 // written here, which is also the reference's (sbt.c:134-259), so the subband samples agree bit for bit.
 template <int N> struct AnalysisDct {
-    static __device__ __forceinline__ void run(const float *x, float *X, const float *tw)
+    template <class T>
+    static __device__ __forceinline__ void run(const T *x, T *X, const float *tw)
     {
         constexpr int H = N / 2;
-        float even[H], u[H], E[H], O[H];
+        T even[H], u[H], E[H], O[H];
         u[H - 1] = x[N - 1];
         even[H - 1] = x[N - 2];
 #pragma unroll
@@ -46,31 +49,34 @@ template <int N> struct AnalysisDct {
         AnalysisDct<H>::run(u, O, tw);
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            const float r = tw[H + j] * O[j];
+            const T r = tw[H + j] * O[j];
             X[j] = E[j] + r;
             X[N - 1 - j] = E[j] - r;
         }
     }
 };
 template <> struct AnalysisDct<1> {
-    static __device__ __forceinline__ void run(const float *x, float *X, const float *) { X[0] = x[0]; }
+    template <class T>
+    static __device__ __forceinline__ void run(const T *x, T *X, const float *) { X[0] = x[0]; }
 };
 
-// One lane = one time slot: 512-tap window folded to 32 values, then the 32-point DCT.
-// A workgroup stages the interleaved stereo PCM of K1_GPB granules (plus 480 samples of history)
-// for both channels with 16-byte loads that are all in flight before the first LDS store; waves
-// 0..3 then work on channel 0, waves 4..7 on channel 1.
-__global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ pcm, long long nsamp,
+// One lane = one time slot of BOTH channels: every value is a (left, right) pair and the arithmetic is packed fp32
+// (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and instruction, each rounded like the plain one), so the
+// window taps, the LDS reads and the instruction stream are shared by the two channels.  A workgroup of four waves
+// stages the interleaved stereo PCM of K1_GPB granules (plus 480 samples of history) as float pairs; a sample pair is
+// one ds_read_b64 (2 LDS cycles per wave; stride 33 pairs between lanes = 66 words: conflict-free), the taps come
+// through the scalar cache.  Round 3: 1.165 -> 0.865 ms per 1024 x 256 frames against one channel per lane with
+// ds_read2_b32 samples and taps by LDS broadcast; the kernel now moves 3.6 GB in that time and is bound by HBM.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(K1_THREADS) void k_polyphase(const int16_t *__restrict__ pcm, long long nsamp,
                                                    const HxStream *__restrict__ st,
                                                    const HxParams *__restrict__ prm,
                                                    const HxGlobalTabs *__restrict__ gt,
                                                    float *__restrict__ sb, int NG, int SG,
                                                    const float *__restrict__ pcmf, int nchan, int *__restrict__ eng, int lsf)
 {
-    __shared__ float xs2[2][K1_LDS];
-    __shared__ __attribute__((aligned(16))) float wr[512];
-    wr[threadIdx.x] = gt->anwin_r[threadIdx.x];
-    const int s = blockIdx.x, ch = threadIdx.x >> 8, lt = threadIdx.x & 255;
+    __shared__ __attribute__((aligned(16))) v2f xs[K1_LDS];
+    const int s = blockIdx.x, lt = threadIdx.x;
     const int g0 = blockIdx.y * K1_GPB;
     const int ng = min(K1_GPB, NG - g0);
     const int count = 480 + 576 * ng;
@@ -79,109 +85,125 @@ __global__ __launch_bounds__(512) void k_polyphase(const int16_t *__restrict__ p
     const int16_t *src = pcm + (long long) s * nsamp * nchan;   // interleaved L R (or one channel)
     const long long n0 = 576LL * g0 - 480;                      // sample index of staged slot 0
     const int hist = (g0 == 0) ? 480 : 0;                       // slots that come from the carry
-    if (nchan == 1) {       // mono batch: channel 1 of the subband buffer stays silent (zeros)
+    if (nchan == 1) {       // mono batch: the right half of every pair is silence
         const float *srcf = pcmf + (long long) s * nsamp;
-        for (int idx = hist + threadIdx.x; idx < count; idx += 512)
-            xs2[0][idx + (idx >> 5)] = pcmf ? srcf[n0 + idx] : (float) src[n0 + idx];
+        for (int idx = hist + lt; idx < count; idx += K1_THREADS)
+            xs[idx + (idx >> 5)] = v2f{pcmf ? srcf[n0 + idx] : (float) src[n0 + idx], 0.0f};
     } else if (pcmf) {      // DC-blocked input from k_dcfilter: fp32, interleaved like the PCM
-        const float2 *srcf = reinterpret_cast<const float2 *>(pcmf) + (long long) s * nsamp;
-        for (int idx = hist + threadIdx.x; idx < count; idx += 512) {
-            const float2 v = srcf[n0 + idx];
-            xs2[0][idx + (idx >> 5)] = v.x;
-            xs2[1][idx + (idx >> 5)] = v.y;
-        }
+        const v2f *srcf = reinterpret_cast<const v2f *>(pcmf) + (long long) s * nsamp;
+        for (int idx = hist + lt; idx < count; idx += K1_THREADS) xs[idx + (idx >> 5)] = srcf[n0 + idx];
     } else if ((reinterpret_cast<unsigned long long>(pcm) & 15ull) == 0) {
         const int nv = count >> 2, vh = hist >> 2;              // 4 stereo samples per 16 bytes
-        int4 w[5];
+        constexpr int NR = ((480 + 576 * K1_GPB) / 4 + K1_THREADS - 1) / K1_THREADS;
+        int4 w[NR];
 #pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const int v = threadIdx.x + 512 * r;
+        for (int r = 0; r < NR; r++) {
+            const int v = lt + K1_THREADS * r;
             const int vc = min(max(v, vh), nv - 1);
             w[r] = *reinterpret_cast<const int4 *>(src + 2 * (n0 + 4LL * vc));
         }
 #pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const int v = threadIdx.x + 512 * r;
+        for (int r = 0; r < NR; r++) {
+            const int v = lt + K1_THREADS * r;
             if (v >= vh && v < nv) {
                 const int q[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int idx = 4 * v + e, o = idx + (idx >> 5);
-                    xs2[0][o] = (float) (short) (q[e] & 0xFFFF);
-                    xs2[1][o] = (float) (short) (q[e] >> 16);
+                    const int idx = 4 * v + e;
+                    xs[idx + (idx >> 5)] = v2f{(float) (short) (q[e] & 0xFFFF), (float) (short) (q[e] >> 16)};
                 }
             }
         }
     } else {
-        for (int idx = hist + threadIdx.x; idx < count; idx += 512) {
+        for (int idx = hist + lt; idx < count; idx += K1_THREADS) {
             const long long n = n0 + idx;
-            xs2[0][idx + (idx >> 5)] = (float) src[2 * n];
-            xs2[1][idx + (idx >> 5)] = (float) src[2 * n + 1];
+            xs[idx + (idx >> 5)] = v2f{(float) src[2 * n], (float) src[2 * n + 1]};
         }
     }
-    for (int idx = threadIdx.x; idx < nchan * hist; idx += 512) {
-        const int c = idx >= 480, i = idx - 480 * c;
-        xs2[c][i + (i >> 5)] = ss->pcm_hist[c][i];
-    }
+    for (int i = lt; i < hist; i += K1_THREADS) xs[i + (i >> 5)] = v2f{ss->pcm_hist[0][i], nchan == 2 ? ss->pcm_hist[1][i] : 0.0f};
     __syncthreads();
     const int gl = lt / 18, t = lt - gl * 18;
     if (gl >= ng) return;
-    // transient detector input (reference detect.c:147-196): energy of subbands 4..17 (MPEG-2 LSF rates: 8..27) per pair
-    // of time slots, as mB; eng index g <-> the granule one before coded granule g, so this granule's go to index + 1
-    // (the last granule's are next call's index 0, which k_attack_eng forms from the carry).
-    int *eo = (!(t & 1) && g0 + gl + 1 < NG) ? eng + ((long long) (s * 2 + ch) * NG + g0 + gl + 1) * 9 + (t >> 1) : nullptr;
-    if (ch >= nchan) {      // mono batch: the silent second channel
-        if (eo) *eo = hx_mblog(gt->mblog, 7.0e4f);
-        return;
-    }
-    const float *xs = xs2[ch];
     const int base = 480 + 576 * gl + 32 * t + 31;          // newest sample of the slot
-    const float *P = xs + (base + (base >> 5) - 526);       // P[526 - pad(off)] = sample of age off
+    // (volatile: single ds_read_b64, 2 LDS cycles each; merged into ds_read2_b64 a pair would take 8)
+    typedef const volatile v2f __attribute__((address_space(3))) *LdsPairPtr;
+    LdsPairPtr P = (LdsPairPtr) (xs + (base + (base >> 5) - 526));      // P[526 - pad(off)] = sample of age off
 #define XS(off) P[526 - ((off) + ((off) >> 5))]
-    // window taps from LDS in use order: four per 16-byte broadcast read
-    float b[32], X[32];
-    {
-        const float4 *w4 = reinterpret_cast<const float4 *>(wr);
-        float s1 = 0.0f;
+    // Two-stage pipeline over the 32 folded window lines, pinned with scheduling barriers: the 16 sample pairs of line
+    // k + 1 are in flight while line k is summed.
+    v2f b[32], X[32];
+    v2f xa[2][8], xb[2][8];
+    // The taps are the same for every lane: scalar loads into SGPRs, two lines ahead (a scalar load returns out of order,
+    // so waiting for one means lgkmcnt(0): that wait stands at the top of a step, where the step's sample pairs are due
+    // anyway, and the next line's reads are issued behind it).
+    const float *wg = gt->anwin_r;
+    float w[3][16];
+#define K1_WLOAD(k) { _Pragma("unroll") for (int i = 0; i < 16; i++) w[(k) % 3][i] = wg[16 * (k) + i]; }
+#define K1_TAP(k, i) w[(k) % 3][i]
+#define K1_LOAD(k) { \
+        const int A_ = ((k) == 0) ? 16 : ((k) <= 16) ? 16 + (k) : 80 - (k); \
+        const int B_ = ((k) <= 16) ? 16 - (k) : 16 + (k); \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) { \
+            xa[(k) & 1][2 * j] = XS(A_ + 128 * j); \
+            xa[(k) & 1][2 * j + 1] = XS(A_ + 128 * j + 64); \
+            if ((k) != 0) { xb[(k) & 1][2 * j] = XS(B_ + 128 * j); xb[(k) & 1][2 * j + 1] = XS(B_ + 128 * j + 64); } \
+        } }
+    K1_LOAD(0)
+    K1_WLOAD(0)
+    K1_WLOAD(1)
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 2 < 32) K1_WLOAD(k + 2)
+        if (k + 1 < 32) K1_LOAD(k + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        v2f s1 = {0.0f, 0.0f}, s2 = {0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float4 w = w4[j];
-            s1 += w.x * XS(16 + 128 * j);
-            s1 += w.z * XS(16 + 128 * j + 64);
+            // (tap * pair: the packed multiply's operand selectors splat the SGPR over both channels)
+            const float c0x = K1_TAP(k, 4 * j), c0y = K1_TAP(k, 4 * j + 1), c1x = K1_TAP(k, 4 * j + 2), c1y = K1_TAP(k, 4 * j + 3);
+            s1 += c0x * xa[k & 1][2 * j];
+            if (k) s2 += c0y * xb[k & 1][2 * j];
+            s1 += c1x * xa[k & 1][2 * j + 1];
+            if (k) s2 += c1y * xb[k & 1][2 * j + 1];
         }
-        b[0] = s1;
+        b[k] = k ? s1 + s2 : s1;
+        __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int k = 1; k < 32; k++) {
-        const int A = (k <= 16) ? 16 + k : 80 - k;
-        const int B = (k <= 16) ? 16 - k : 16 + k;
-        const float4 *w4 = reinterpret_cast<const float4 *>(wr + 16 * k);
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float4 w = w4[j];
-            s1 += w.x * XS(A + 128 * j);
-            s2 += w.y * XS(B + 128 * j);
-            s1 += w.z * XS(A + 128 * j + 64);
-            s2 += w.w * XS(B + 128 * j + 64);
-        }
-        b[k] = s1 + s2;
-    }
+#undef K1_LOAD
+#undef K1_WLOAD
+#undef K1_TAP
 #undef XS
     AnalysisDct<32>::run(b, X, p->dct_tw);
-    float *out = sb + ((long long) (s * 2 + ch) * SG + (g0 + gl + 3)) * 576 + t;
+    float *out = sb + ((long long) (s * 2) * SG + (g0 + gl + 3)) * 576 + t;
 #pragma unroll
-    for (int k = 0; k < 32; k++) out[18 * k] = X[k];
-    {   // slots 2 k (this lane) and 2 k + 1 (the next lane), subband after subband, in the reference's order of additions
-        float sum = 7.0e4f;
+    for (int k = 0; k < 32; k++) out[18 * k] = X[k].x;
+    if (nchan == 2) {
+        float *out1 = out + (long long) SG * 576;
+#pragma unroll
+        for (int k = 0; k < 32; k++) out1[18 * k] = X[k].y;
+    }
+    {   // transient detector input (reference detect.c:147-196): energy of subbands 4..17 (MPEG-2 LSF rates: 8..27) per pair
+        // of time slots, as mB: slots 2 k (this lane) and 2 k + 1 (the next lane), subband after subband, in the reference's
+        // order of additions.  eng index g <-> the granule one before coded granule g, so this granule's go to index + 1
+        // (the last granule's are next call's index 0, which k_attack_eng forms from the carry).  A mono batch's silent
+        // second channel sums to the floor by itself.
+        v2f sum = {7.0e4f, 7.0e4f};
+#define ENG_TERM(i) { const v2f y1 = {__shfl_down(X[i].x, 1, 64), __shfl_down(X[i].y, 1, 64)}; v2f x = X[i] * X[i]; sum += x; x = y1 * y1; sum += x; }
         if (!lsf) {
 #pragma unroll
-            for (int i = 4; i < 18; i++) { const float y1 = __shfl_down(X[i], 1, 64); float x = X[i] * X[i]; sum += x; x = y1 * y1; sum += x; }
+            for (int i = 4; i < 18; i++) ENG_TERM(i)
         } else {
 #pragma unroll
-            for (int i = 8; i < 28; i++) { const float y1 = __shfl_down(X[i], 1, 64); float x = X[i] * X[i]; sum += x; x = y1 * y1; sum += x; }
+            for (int i = 8; i < 28; i++) ENG_TERM(i)
         }
-        if (eo) *eo = hx_mblog(gt->mblog, sum);
+#undef ENG_TERM
+        if (!(t & 1) && g0 + gl + 1 < NG) {
+            int *eo = eng + ((long long) (s * 2) * NG + g0 + gl + 1) * 9 + (t >> 1);
+            eo[0] = hx_mblog(gt->mblog, sum.x);
+            eo[(long long) NG * 9] = hx_mblog(gt->mblog, sum.y);
+        }
     }
 }
 
