@@ -134,6 +134,7 @@ struct alignas(16) AllocLds {
     const double *pow43;                // HxGlobalTabs::pow43 (global memory)
     int *big_counter;                   // device counter of line passes that took the double table (tests)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
+    alignas(4) unsigned char gflag[256];        // block type | stereo decision << 2 of the next 256 granules (frame loop, hx_alloc3.inc)
 #ifdef HX_PROFILE
     unsigned prof[64];                  // (the profile build holds three workgroups per CU instead of four: per-stream cycles are what it is for)
 #endif

@@ -20,7 +20,7 @@ prof = b.debug_read("prof", np.uint64, S * 64).reshape(S, 64).astype(np.float64)
 names = {0: "join wait", 1: "startup", 2: "seek_initial", 3: "seek_actual", 4: "trade_dual", 5: "scale_factors", 6: "big_lucky", 7: "do_quant", 8: "quant+count", 9: "increase_bits",
          10: "decrease_bits", 11: "inverse_sf2", 12: "bitallo total", 13: "hand-over", 17: "placement", 20: "#sweeps", 21: "#lucky passes", 22: "#counts", 31: "kernel total",
          23: "lucky: setup", 24: "lucky: terms", 25: "lucky: sums", 26: "lucky: replay", 27: "sweep: publish", 28: "sweep: lines", 29: "sweep: sums",
-         36: "cnt: ballots", 37: "cnt: j2/j3", 38: "cnt: regions", 39: "cnt: pairs", 40: "cnt: quads", 41: "cnt: reduce", 42: "q+c: post", 43: "q+c: quant", 44: "q+c: join", 30: "seek: join wait", 45: "#sweeps helper"}
+         36: "cnt: ballots", 37: "cnt: j2/j3", 38: "cnt: regions", 39: "cnt: pairs", 40: "cnt: quads", 41: "cnt: reduce", 42: "q+c: post", 43: "q+c: quant", 44: "q+c: join", 30: "seek: join wait", 45: "#sweeps helper", 14: "frame budget", 15: "gr: pre", 16: "gr: fetch post", 18: "retire", 19: "pack_sf", 46: "pl: granule tail", 47: "pl: sizes", 48: "pl: slot", 49: "pl: head+gr copy"}
 order = np.argsort(prof[:, 31])
 top = order[-10:]
 print("streams by kernel total (k cycles per frame): min %.0f  mean %.0f  p95 %.0f  p99 %.0f  max %.0f" % tuple(x / F / 1e3 for x in (
