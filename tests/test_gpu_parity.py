@@ -854,6 +854,23 @@ def test_long_run_many_ragged_calls(kw):
     b.close()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(bitrate=64, mode=0), dict(samprate=22050, bitrate=32), dict(samprate=16000, mode=2, bitrate=16)],
+                         ids=["vbr50_sw", "cbr128_lr_sw", "lsf_cbr64_22k", "a1_dual_16k"])
+def test_one_call_longer_than_the_flag_staging_block(kw):
+    """300 frames in ONE call: the stream walk stages the granules' block types and stereo decisions in LDS 128 frames at
+    a time (hx_alloc3.inc), so a call this long crosses two refills - with block switching and changing M/S decisions on
+    both sides of them, for the MPEG-1, MPEG-2 and first-generation kernels"""
+    sr = kw.get("samprate", 44100)
+    S, F = 4, 300
+    pcm = np.stack([synth.stream_pcm(900 + i, F, sr=sr, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    for s in range(S):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    b.close()
+
+
 def test_api_misuse_fails_loudly_and_leaves_the_batch_usable():
     a = api()
     with pytest.raises(RuntimeError):           # mono and stereo streams cannot share a batch
