@@ -347,7 +347,9 @@ __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl
 // in separate LDS arrays, so the waves never wait for each other inside a search).  Band lane i < 32
 // passes the gain step g it wants measured (-1: none) and gets the band's noise back in a register;
 // sbeg / send are the lane's band limits, kept by the caller.
-__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int ch, int g, int sbeg, int send, int nlines)
+// (ig, gn = the step's gain pair 1 / gain^(3/4), gain: the caller reads the tables a sweep ahead, see seek_actual_ch;
+// x34max, logcbw = the band lane's constants, kept by the caller)
+__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int ch, int g, float ig_g, float gn_g, float x34max, int logcbw, int sbeg, int send, int nlines)
 {
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
     // and the line range that any evaluated band touches: the bands lie in lane order, so it runs from the first
@@ -355,9 +357,9 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     bool bslow = false;
     PROF_T0();
     if (LANE < NB) {
-        const float ig = (g >= 0) ? L.look_34igain[g] : -1.0f;
-        L.gpair[ch][LANE] = make_float2(ig, (g >= 0) ? L.look_gain[g] : 0.0f);
-        if (g >= 0) bslow = noise_band_needs_pow(ig, L.x34max[ch][LANE]);
+        const float ig = (g >= 0) ? ig_g : -1.0f;
+        L.gpair[ch][LANE] = make_float2(ig, (g >= 0) ? gn_g : 0.0f);
+        if (g >= 0) bslow = noise_band_needs_pow(ig, x34max);
     }
     const unsigned long long evald = __ballot(LANE < NB && g >= 0);
     int lo = 576, hi = 0;
@@ -375,7 +377,7 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     int noise = 0;
     if (g >= 0) {
         const float sxx = band_sum(&L.term[ch][sbeg], send - sbeg, 0.0f);
-        noise = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[LANE];
+        noise = hx_mblog(L.mblog, 1.0e-12f + sxx) - logcbw;
     }
     SYNC();
     PROF_ACC(29);
@@ -506,19 +508,34 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
     SweepRegs R;
     const int nl = p->nbmax[ch];
     sweep_load(L, R, ch);
+    // The gain pair of a step comes from two tables in LDS.  A walking band's next step is known before the current
+    // one is measured (one down or one up), so its pair is read a sweep ahead and the sweep starts without that
+    // round trip; the first measurement reads both neighbours.  (Indices are clamped for the reads only: a step
+    // that would leave the table is never evaluated - niter / the gain limits stop the walk first.)
+    const int ib = min(i, NB - 1);
+    const float x34max = L.x34max[ch][ib];
+    const int logcbw = L.logcbw[ib];
+    float ig_c = L.look_34igain[s & 127], gn_c = L.look_gain[s & 127];      // pair of the step to measure now
+    float ig_dn = 0.0f, gn_dn = 0.0f, ig_up = 0.0f, gn_up = 0.0f;          // pairs of the steps below / above it
     SYNC();
     while (__any(mode != 0)) {
         PROF_CNT(20);
 #ifdef HX_PROFILE
         if (threadIdx.x == 64) L.prof[45] += 1;     // the helper wave's sweeps (channel 1)
 #endif
-        const int noise = noise_sweep(L, R, ch, (mode == 0) ? -1 : (mode == 1 ? s : t), sbeg, send, nl);
+        const int gcur = (mode == 0) ? -1 : (mode == 1 ? s : t);
+        {   // requested now, used after this sweep
+            const int gq = max(gcur, 0);
+            if (mode != 3) { ig_dn = L.look_34igain[max(gq - 1, 0)]; gn_dn = L.look_gain[max(gq - 1, 0)]; }
+            if (mode != 2) { ig_up = L.look_34igain[min(gq + 1, 127)]; gn_up = L.look_gain[min(gq + 1, 127)]; }
+        }
+        const int noise = noise_sweep(L, R, ch, gcur, ig_c, gn_c, x34max, logcbw, sbeg, send, nl);
         if (mode == 1) {
             const int dn = noise - NTarget;
             ntadj += (dn >> 3);
             absmin = abs(dn); tnmin = noise; smin = s; iter = 0;
-            if (dn > 100) { t = s - 1; niter = min(t, 20); mode = (niter > 0) ? 2 : 0; }
-            else if (dn < -100) { t = s + 1; niter = 20; mode = 3; }
+            if (dn > 100) { t = s - 1; niter = min(t, 20); mode = (niter > 0) ? 2 : 0; ig_c = ig_dn; gn_c = gn_dn; }
+            else if (dn < -100) { t = s + 1; niter = 20; mode = 3; ig_c = ig_up; gn_c = gn_up; }
             else mode = 0;
         } else if (mode == 2 || mode == 3) {
             const int ad = abs(noise - NTarget);
@@ -526,7 +543,8 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
             iter++;
             const bool stop = (mode == 2) ? (noise <= NTarget) : (noise >= NTarget);
             if (stop || iter >= niter) mode = 0;
-            else t += (mode == 2) ? -1 : 1;
+            else if (mode == 2) { t -= 1; ig_c = ig_dn; gn_c = gn_dn; }
+            else { t += 1; ig_c = ig_up; gn_c = gn_up; }
         }
     }
     if (band) { L.gsf[ch][i] = smin; L.Noise[ch][i] = tnmin; L.NTadjust[ch][i] = ntadj; }

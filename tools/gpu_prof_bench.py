@@ -7,9 +7,12 @@ import bench
 from hmp3_amd import api
 S, F = 1024, int(os.environ.get("PF", "256"))
 dev = torch.device("cuda:0")
-pcm = bench.synth_batch_gpu(torch, np, S, F, [44100] * S, [0.7] * S, False, dev)
+CFG = int(os.environ.get("PF_CFG", "2"))         # 2: CBR-128 long blocks; 3: VBR-50 with block switching (1024 of its streams)
+w = bench.workload(CFG)
+kw, sr = w["classes"][0]
+pcm = bench.synth_batch_gpu(torch, np, S, F, [sr] * S, [w["rho"][i % len(w["rho"])] for i in range(S)], w["bursts"], dev)
 st = torch.cuda.current_stream().cuda_stream
-b = api.Batch(api.default_control(bitrate=64, short_block_threshold=99999), nstreams=S, max_frames=F)
+b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
 b.debug_enable(True)
 stride = b.out_stride(F)
 out = torch.empty((S, stride), dtype=torch.uint8, device=dev); nb = torch.zeros((S,), dtype=torch.int32, device=dev)
