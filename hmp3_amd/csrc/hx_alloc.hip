@@ -255,10 +255,12 @@ __device__ __forceinline__ float noise_xhat_big(const AllocLds &L, int qx, doubl
 // Table-only variant for the hot loops: the index is clamped into the table, and the caller has
 // established per band (from the band's largest x^(3/4), the index is monotone in it) that no
 // line needs the pow() path - or repairs the band's lines afterwards.
+// (The reference rounds half away from zero, tmp + copysign(0.5, tmp).  Here tmp >= -0.0946 for every line that is read
+// afterwards - igain > 0, x34 >= 0 - and on [-0.0946, 0) both tmp - 0.5 and tmp + 0.5 truncate to 0: one instruction less.)
 __device__ __forceinline__ float noise_term_fast(const AllocLds &L, float igain, float gain, float x34, float x)
 {
     float tmp = (igain * x34 + (0.0f - 0.0946f));
-    const unsigned qx = (unsigned) (int) (tmp + copysignf(0.5f, tmp));
+    const unsigned qx = (unsigned) (int) (tmp + 0.5f);
     const float xhat = gain * L.look_ix43[min(qx, 255u)];
     tmp = x - xhat;
     return tmp * tmp;
