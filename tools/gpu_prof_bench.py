@@ -10,7 +10,8 @@ dev = torch.device("cuda:0")
 CFG = int(os.environ.get("PF_CFG", "2"))         # 2: CBR-128 long blocks; 3: VBR-50 with block switching (1024 of its streams)
 w = bench.workload(CFG)
 kw, sr = w["classes"][0]
-pcm = bench.synth_batch_gpu(torch, np, S, F, [sr] * S, [w["rho"][i % len(w["rho"])] for i in range(S)], w["bursts"], dev)
+rho_list = [float(os.environ["PF_RHO"])] if "PF_RHO" in os.environ else w["rho"]     # PF_RHO=1.0: the loud near-mono case
+pcm = bench.synth_batch_gpu(torch, np, S, F, [sr] * S, [rho_list[i % len(rho_list)] for i in range(S)], w["bursts"], dev)
 st = torch.cuda.current_stream().cuda_stream
 b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=F)
 b.debug_enable(True)
