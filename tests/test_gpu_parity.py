@@ -871,6 +871,34 @@ def test_one_call_longer_than_the_flag_staging_block(kw):
     b.close()
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=64), dict(bitrate=64, mode=3)], ids=["stereo", "mono"])
+def test_device_pcm_pointer_without_16_byte_alignment(kw):
+    """k_polyphase stages the PCM with 16-byte loads when the caller's pointer allows it and sample by sample when it
+    does not: a device buffer that starts 4 (stereo) / 2 (mono) bytes past an aligned address takes the second way"""
+    import torch
+    mono = kw.get("mode") == 3
+    S, F = 3, 9
+    pcm = np.stack([synth.stream_pcm(70 + i, F, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    if mono:
+        pcm = np.ascontiguousarray(pcm[:, :, 0])
+    dev = torch.device("cuda:0")
+    flat = torch.zeros(pcm.size + 8, dtype=torch.int16, device=dev)
+    off = 1 if mono else 2                      # int16 elements
+    flat[off:off + pcm.size] = torch.from_numpy(pcm.reshape(-1)).to(dev)
+    assert (flat.data_ptr() + 2 * off) % 16 != 0
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    stride = b.out_stride(F)
+    d_out = torch.zeros((S, stride), dtype=torch.uint8, device=dev); d_nb = torch.zeros((S,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    b.encode_device(flat.data_ptr() + 2 * off, F, d_out.data_ptr(), stride, d_nb.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert b.status() == 0
+    o, nb = d_out.cpu().numpy(), d_nb.cpu().numpy()
+    for s in range(S):
+        assert o[s, :nb[s]].tobytes() == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    b.close()
+
+
 def test_api_misuse_fails_loudly_and_leaves_the_batch_usable():
     a = api()
     with pytest.raises(RuntimeError):           # mono and stereo streams cannot share a batch
