@@ -615,7 +615,12 @@ __global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, cons
     __shared__ SpecTabs T;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sbnd = lane & 31, ch = lane >> 5;
     for (int i = threadIdx.x; i < 256; i += 128) { T.mblog[i] = gt->mblog[i]; T.mbexp_lo[i] = gt->mbexp_lo[i]; T.mbexp_hi[i] = gt->mbexp_hi[i]; }
-    const long long sg = (long long) blockIdx.x * 2 + wv;           // (s, g); S * NG is even
+    // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own; neighbouring granules share a subband
+    // block, so every XCD gets a contiguous piece of the grid: workgroups b and b + 8, launched together on one XCD, are
+    // neighbours in the stream, and the second read of the shared block hits that L2 (speed only: any placement is correct)
+    const unsigned nwg = gridDim.x, cpx = nwg >> 3;
+    const unsigned wg = (blockIdx.x < (cpx << 3)) ? (blockIdx.x & 7) * cpx + (blockIdx.x >> 3) : blockIdx.x;
+    const long long sg = (long long) wg * 2 + wv;                   // (s, g); S * NG is even
     const int g = (int) (sg % NG), s = (int) (sg / NG);
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(st[s].cls);      // wave-uniform: table reads become scalar loads
     float (*in)[2][576] = in_s[wv];
