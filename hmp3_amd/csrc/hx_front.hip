@@ -613,7 +613,9 @@ __global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, cons
     __shared__ float xtab_s[2][2][64];
     __shared__ float es_s[2][3][64];
     __shared__ SpecTabs T;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sbnd = lane & 31, ch = lane >> 5;
+    // (the wave index is wave-uniform, which the compiler cannot see in threadIdx: through readfirstlane the granule's
+    // addresses are scalar arithmetic)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sbnd = lane & 31, ch = lane >> 5;
     for (int i = threadIdx.x; i < 256; i += 128) { T.mblog[i] = gt->mblog[i]; T.mbexp_lo[i] = gt->mbexp_lo[i]; T.mbexp_hi[i] = gt->mbexp_hi[i]; }
     // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own; neighbouring granules share a subband
     // block, so every XCD gets a contiguous piece of the grid: workgroups b and b + 8, launched together on one XCD, are
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
     __shared__ int t_mblog[256];
     for (int i = threadIdx.x; i < 256; i += 64 * PREP_GPB) { t_exp[i] = gt->pow34_exp[i]; t_mblog[i] = gt->mblog[i]; }
     if (threadIdx.x < 16) { t_a[threadIdx.x] = gt->pow34_a[threadIdx.x]; t_b[threadIdx.x] = gt->pow34_b[threadIdx.x]; }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (lane < 44) xmax[wv][lane / 22][lane % 22] = 0;
     __syncthreads();
     const long long unit = (long long) blockIdx.x * PREP_GPB + wv;      // (s, g)

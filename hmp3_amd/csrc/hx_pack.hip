@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
                                               int *__restrict__ status, int frames_per_stream, int NG, int lsf, long long nframes_total)
 {
     __shared__ PackLds L;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform, made provably so)
     for (int i = tid; i < 1408; i += 256) { L.huff_code[i] = gt->huff_code[i]; L.huff_len[i] = gt->huff_len[i]; }
     if (tid < 32) {
         const int dim = (tid >= 16) ? 16 : gt->huff_dim[tid], lin = (tid >= 16) ? gt->huff_lin[tid] : 0;
