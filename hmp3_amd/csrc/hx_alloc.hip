@@ -311,34 +311,34 @@ __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int
 }
 
 // The same sweep when some evaluated band may quantise beyond the float table (decided per sweep from the band
-// maxima; loud near-mono material at low gain steps): terms beyond the table come from the double table in global
-// memory.  Inline and on the caller's line registers since round 3: out of line and re-reading its operands from LDS
-// (round 1, when the kernel spilled at 256 registers) it cost the loud streams 4 % of their time; with the registers
-// that -disable-machine-licm freed the common path does not notice it.  (Bands that are not evaluated quantise to <= 0.)
-__device__ __forceinline__ void sweep_lines_big(AllocLds &L, const SweepRegs &R, int ch, int lo, int nl)
+// maxima; loud near-mono material at low gain steps): terms beyond the table come from the double table.  Out of
+// line and from LDS instead of the caller's registers, three lines at a time, so that the rare case costs the common
+// path neither registers nor code.  (Bands that are not evaluated quantise to <= 0.)
+__device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl)
 {
     if (LANE == 0) atomicAdd(L.big_counter, 1);
-#pragma unroll
+#pragma unroll 1
     for (int c3 = 0; c3 < 3; c3++) {
         if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
-        float t[3], gn[3];
+        float t[3], gn[3], xr[3];
         int qx[3];
         double pw[3];
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) {
-            const int k = 3 * c3 + k3;
-            const float2 gp = L.gpair[ch][R.bnd[k]];
-            const float ig = gp.x;
+            const int j = LANE + 64 * (3 * c3 + k3), bnd = L.band_of_line[j];
+            const float2 gp = L.gpair[ch][bnd];
+            const float ig = gp.x, x34 = L.x34[ch][j];
             gn[k3] = gp.y;
-            const float tmp = (ig * R.x34[k] + (0.0f - 0.0946f));
+            xr[k3] = L.xr[ch][j];
+            const float tmp = (ig * x34 + (0.0f - 0.0946f));
             qx[k3] = (int) (tmp + copysignf(0.5f, tmp));
-            t[k3] = noise_term_fast(L, ig, gn[k3], R.x34[k], R.xr[k]);
+            t[k3] = noise_term_fast(L, ig, gn[k3], x34, xr[k3]);
         }
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) pw[k3] = L.pow43[min(max(qx[k3], 0), HX_POW43_N - 1)];
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++)
-            if (qx[k3] >= 256) { const float d = R.xr[3 * c3 + k3] - noise_xhat_big(L, qx[k3], pw[k3], gn[k3]); t[k3] = d * d; }
+            if (qx[k3] >= 256) { const float d = xr[k3] - noise_xhat_big(L, qx[k3], pw[k3], gn[k3]); t[k3] = d * d; }
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
     }
@@ -372,7 +372,7 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     SYNC();
     PROF_ACC(27);
     const int nl = min(nlines, hi);
-    if (__builtin_expect(__any(bslow), 0)) sweep_lines_big(L, R, ch, lo, nl);
+    if (__builtin_expect(__any(bslow), 0)) sweep_lines_big(L, ch, lo, nl);
     else sweep_lines(L, R, ch, lo, nl);
     SYNC();
     PROF_ACC(28);
