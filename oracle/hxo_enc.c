@@ -420,7 +420,7 @@ static int encode_joint(hxo_encoder *e, hxo_bitw *w)
     TargetBits = p->AveTargetBits + p->AveTargetBits;
     bit_pool = s->byte_pool << 2;
     bit_max = s->byte_max << 2;
-    bit_min = s->byte_min << 2;
+    bit_min = s->byte_min * (1 << 2);        /* (may be negative: a multiplication, not a shift) */
     sf_bits = p->sf_bit_max + p->sf_bit_max;
     ba_bit_max = bit_max - sf_bits;
     ba_bit_min = bit_min - sf_bits;
@@ -507,7 +507,7 @@ static int encode_single(hxo_encoder *e, hxo_bitw *w)
 
     bit_pool = s->byte_pool << 2;
     bit_max = s->byte_max << 2;
-    bit_min = s->byte_min << 2;
+    bit_min = s->byte_min * (1 << 2);        /* (may be negative: a multiplication, not a shift) */
     ba_bit_max = bit_max;
     if (ba_bit_max > 4095) ba_bit_max = 4095;
     ba_bit_min = bit_min;
@@ -573,7 +573,7 @@ static int encode_joint_a1(hxo_encoder *e, hxo_bitw *w)
     TargetBits = p->AveTargetBits + p->AveTargetBits;
     ba_bit_max = s->byte_max << 2;
     if (ba_bit_max > 4095) ba_bit_max = 4095;
-    ba_bit_min = s->byte_min << 2;
+    ba_bit_min = s->byte_min * (1 << 2);        /* (may be negative: a multiplication, not a shift) */
     sf_bits = p->sf_bit_max + p->sf_bit_max;
     ba_bit_max -= sf_bits;
     ba_bit_min -= sf_bits;
@@ -623,7 +623,7 @@ static int encode_single_a1(hxo_encoder *e, hxo_bitw *w)
     const hxo_params *p = &e->p;
     int ch, igr, bits, ba_bit_min, ba_bit_max, ba_min, ba_max;
     ba_bit_max = s->byte_max << 1;          /* two channels share the frame */
-    ba_bit_min = s->byte_min << 1;
+    ba_bit_min = s->byte_min * (1 << 1);        /* (may be negative: a multiplication, not a shift) */
     if (ba_bit_max > 4095) ba_bit_max = 4095;
     ba_bit_max -= p->sf_bit_max;
     ba_bit_min -= p->sf_bit_max;
@@ -672,7 +672,7 @@ static int encode_granule_lsf_a1(hxo_encoder *e, hxo_bitw *w, int igr)
     int ch, bits, bit_min, bit_max, ba_min, ba_max, ms = 0;
     if (p->h_mode == 2) {
         bit_max = s->byte_max << 2;
-        bit_min = s->byte_min << 2;
+        bit_min = s->byte_min * (1 << 2);        /* (may be negative: a multiplication, not a shift) */
         ba_max = HXO_MIN(bit_max, 4095) - p->sf_bit_max;
         ba_min = bit_min - p->sf_bit_max;
         transform_granule(e, igr);
@@ -697,7 +697,7 @@ static int encode_granule_lsf_a1(hxo_encoder *e, hxo_bitw *w, int igr)
         return 0;
     }
     bit_max = s->byte_max << 3;
-    bit_min = s->byte_min << 3;
+    bit_min = s->byte_min * (1 << 3);        /* (may be negative: a multiplication, not a shift) */
     if (s->byte_pool > 245) bit_min += 40;
     ba_max = HXO_MIN(bit_max, 4095) - 2 * p->sf_bit_max;
     ba_min = bit_min - 2 * p->sf_bit_max;
@@ -735,7 +735,7 @@ static int encode_granule_lsf(hxo_encoder *e, hxo_bitw *w, int igr)
 
     bit_pool = s->byte_pool << 3;
     bit_max = s->byte_max << 3;
-    bit_min = s->byte_min << 3;
+    bit_min = s->byte_min * (1 << 3);        /* (may be negative: a multiplication, not a shift) */
     if (p->nchan == 2 && s->byte_pool > 245) bit_min += 40;
     ba_max = bit_max;
     if (ba_max > 4095) ba_max = 4095;

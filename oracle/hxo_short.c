@@ -60,7 +60,7 @@ int hxo_ms_metric_short(hxo_encoder *e, const float xx[2][576])
             if (s1 > 0.95 * s0) d += 2;
         }
     }
-    return (p->nsfs - d) << 10;
+    return (p->nsfs - d) * 1024;     /* (the reference shifts; the value may be negative) */
 }
 
 static int noise_actual(const hxo_params *p, const float *x34, const float *x, int gsf, int n, int logn)
