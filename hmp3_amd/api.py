@@ -51,6 +51,7 @@ EXPORTS = [
     "hx_batch_gate_timeouts", "hx_enc_out_stats", "hx_multi_create", "hx_multi_destroy", "hx_multi_ndevices", "hx_multi_nstreams", "hx_multi_shard", "hx_multi_batch",
     "hx_multi_out_stride", "hx_multi_encode_s16_host", "hx_multi_encode_f32_host", "hx_multi_encode_f32_host_stats", "hx_multi_status",
     "hx_build_id", "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
+    "hx_batch_k6_variant", "hx_batch_resident_streams",
 ]
 
 _lib = None
@@ -268,6 +269,17 @@ class Batch:
 
     def status(self):
         return int(lib().hx_batch_status(self.h))
+
+    def k6_variant(self):
+        """0 = k_alloc (four streams per CU), 1 = k_alloc_slim (six)"""
+        L = lib()
+        L.hx_batch_k6_variant.argtypes = [C.c_void_p]
+        return int(L.hx_batch_k6_variant(self.h))
+
+    def resident_streams(self):
+        L = lib()
+        L.hx_batch_resident_streams.argtypes = [C.c_void_p]
+        return int(L.hx_batch_resident_streams(self.h))
 
     def gate_timeouts(self):
         return int(lib().hx_batch_gate_timeouts(self.h))

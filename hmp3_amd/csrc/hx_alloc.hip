@@ -34,6 +34,7 @@ struct AllocPrm {
     int remainder, divisor, main_framebytes, sf_bit_max, AveTargetBits;
     int ms_flag, hf_flag, vbr_flag;
     int ivbr_min, ivbr_max, vbr_main_framebytes[16], vbr_pool_target;
+    int fbmin, fbmax;                   // main-data capacity of the lowest / highest VBR bitrate index
     int initialMNR, test1;
     int nsf[2], nsf2[2], nsf3[2], nbmax[2], nbmax2[2], nbmax3[2];
     float rnBand_l[22];
@@ -63,25 +64,80 @@ struct alignas(16) Outbox {
     int has_frame;
 };
 
+// HX_SLIM = 1: the low-footprint layout of the stream walk's LDS (26.5 KB instead of 38.3 KB per stream: six workgroups per
+// CU instead of four, for batches with more streams than the chip holds at once).  What differs from the layout it is
+// derived from (all of it bit-identical in its results):
+//  * the quantised lines are int16 and live in the first half of the noise-term buffer: a granule's terms (gain search,
+//    big_lucky) are dead when its lines are quantised and the other way round; inverse_sf2 puts its squares into xr
+//    (in place) and x34, both dead by then, instead of into the term buffer; the quantiser writes every line (zeros past
+//    the coded range), since the buffer holds terms before it;
+//  * the next granule's band start values land in the second half of the term buffer (the order to fetch them goes out
+//    when the lines are final, and they are picked up before the next granule's first term is written);
+//  * a short granule's signs are kept as bits while it is allocated and end up, in bitstream order, in the x34 buffer;
+//  * gain tables, the x^(3/4) exponent table: 2^(k/4) and 2^(-3k/16) have period 4 / 16 in the mantissa, the tables are
+//    ldexp of 4 / 16 constants (hx_host.cpp checks that identity on the host's tables before a batch may use this kernel);
+//    the mB-log and log-subtract tables as 16-bit values;
+//  * the short-block allocator's gain-step arrays and the band tables as int16, the scalefactor outputs as bytes, big_lucky's
+//    work list in an array of its own.
+#ifndef HX_SLIM
+#define HX_SLIM 0
+#endif
+#if HX_SLIM && HX_A1
+#error "the low-footprint layout is built for the second-generation allocator only"
+#endif
+#if HX_SLIM
+typedef short ix_t;                     // a quantised line
+typedef short sgs_t;                    // short-block gain steps / scalefactors per band (0 .. 127, flags 0 / -1)
+typedef signed char sfo_t;              // a scalefactor as transmitted (0 .. 15; the first-generation allocator's -3 .. 999 never get here)
+typedef short btab_t;                   // band tables: widths, first lines, log widths in mB, target tapers
+#else
+typedef int ix_t;
+typedef int sgs_t;
+typedef int sfo_t;
+typedef int btab_t;
+#endif
+
+// The frame loop's carried scalars - bit reservoir, ring positions of the pending frames, layout cursor, running totals - and
+// the budget of the frame being coded.  They live here and are read where a frame is budgeted and where it is placed: as
+// register variables they occupied some sixty scalar registers over all of the allocator's code in between, which the compiler
+// kept in lanes of three VGPRs - and, at the low-footprint build's 168 registers, spilled those to scratch (61 reload sites).
+struct FrameState {
+    int padcount; unsigned main_tot, main_sent, mf_tot;
+    int main_bytes; unsigned side_p0, side_p1, tot_frames_out, tot_bytes_out; int ave_tot;
+    int opos, slot_lo, slot_hi;
+    int pad, byte_pool, byte_max, byte_min, bytesout, pk_first;     // the frame in flight
+};
+
 struct alignas(16) AllocLds {
     float xr[2][576];
     float x34[2][576];
     float term[2][576];
+#if !HX_SLIM
     int ix[2][576];
     unsigned char signx[2][576];
     alignas(16) HxBandPrep band_next;               // the next granule's band start values, landed by LDS-DMA while this granule's are still in use
+#else
+    unsigned long long sgnbits[2][9];               // short blocks: sign of line t of channel c = bit t & 63 of word t >> 6
+#endif
     unsigned char band_of_line[576];
     // tables staged from global memory
-    float look_ix43[256], look_gain[128], look_34igain[128];
+    float look_ix43[256];
+#if !HX_SLIM
+    float look_gain[128], look_34igain[128];
     int mblog[256];
-    float pow34_exp[256], pow34_a[16], pow34_b[16], quant_off[32];
+    float pow34_exp[256];
     int logsub[84];
+#else
+    float gain4[4], igain16[16];                    // look_gain[8 .. 11], look_34igain[8 .. 23]: the tables' mantissa periods
+    unsigned short mblog[256];                      // the table without its constant -38227
+    short logsub[84];
+#endif
+    float pow34_a[16], pow34_b[16], quant_off[32];
     unsigned char huff_len[1408];
     unsigned char sband_of_line[192];
-    int nBand_s[16], startBand_s[16], logcbw_s[16];
-    unsigned short huff_off[32];
-    unsigned char huff_dim[32], huff_lin[32], quada_code[16], quada_len[16];
-    int nBand[NB], startBand[24], logcbw[NB], taper[NB];
+    btab_t nBand_s[16], startBand_s[16], logcbw_s[16];
+    unsigned char quada_len[16];
+    btab_t nBand[NB], startBand[24], logcbw[NB], taper[NB];
     int NTadjust[2][NB];                // long-block gain estimator feedback (persists)
     union {
         struct {    // long blocks: per band working set, [channel][sfb]
@@ -92,6 +148,9 @@ struct alignas(16) AllocLds {
             float gig[2][NB];                   // 1 / gain^(3/4) of the band's quantiser step
             alignas(8) float2 gpair[2][NB];     // gain pair (1 / gain^(3/4), gain) of the band's current evaluation step: one read per line
             int lucky[6][2][13];                // big_lucky_noise: noise of candidate c of band (ch, sfb)
+#if HX_SLIM
+            unsigned short llist[6 * 26 + 4];   // big_lucky_noise: its work list
+#endif
         };
         struct {    // first-generation allocator (hx_alloc1.inc): psy model output and noise / mask levels per band in dB
             int a_pad[17][2][NB];       // (the long-block arrays up to x34max stay in use)
@@ -100,7 +159,7 @@ struct alignas(16) AllocLds {
         };
         struct {    // short blocks: [channel][window][sfb]
             int s_snr[2][3][16], s_Noise0[2][3][16], s_Noise[2][3][16], s_NT[2][3][16];
-            int s_gzero[2][3][16], s_gmin[2][3][16], s_gsf[2][3][16], s_sf[2][3][16], s_active[2][3][16];
+            sgs_t s_gzero[2][3][16], s_gmin[2][3][16], s_gsf[2][3][16], s_sf[2][3][16], s_active[2][3][16];
             int s_ixmax[2][3][16], s_geval[3][16], s_tmpn[3][16], s_maskmb[2][3][16];
             float s_xsxx[2][3][16], s_x34max[2][3][16];
             int s_G[2][3], s_GG[2], s_subgain[2][3];
@@ -122,23 +181,47 @@ struct alignas(16) AllocLds {
     int tmpn[2][NB];
     unsigned int sidew[10];             // bit staging of the side information
     HxGr gr[2][2];
-    int sfout[2][2][NB];
-    int sfs[2][3][12];                  // short-block scalefactors of the current granule
+    sfo_t sfout[2][2][NB];
+    sfo_t sfs[2][3][12];                // short-block scalefactors of the current granule
     AllocPrm P;
+    FrameState fs;
     int tabpk[32];                      // per Huffman table: code offset | row stride << 12 | linbits << 20
     unsigned long long candpk[19];      // candidate tables per class of a region's largest value
     unsigned short r_mf[32];            // pending frames: main-data bytes of the slot ...
     int r_off[32];                      // ... and offset of its header in the output buffer
+#if !HX_SLIM
     float dump[64];                     // per-lane sink for predicated-off stores (keeps hot loops branch-free)
+#endif
     Outbox ob[2];
     const double *pow43;                // HxGlobalTabs::pow43 (global memory)
     int *big_counter;                   // device counter of line passes that took the double table (tests)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
-    alignas(4) unsigned char gflag[256];        // block type | stereo decision << 2 of the next 256 granules (frame loop, hx_alloc3.inc)
+    alignas(4) unsigned char gflag[HX_SLIM ? 64 : 256];     // block type | stereo decision << 2 of the next granules (frame loop, hx_alloc3.inc)
 #ifdef HX_PROFILE
     unsigned prof[64];                  // (the profile build holds three workgroups per CU instead of four: per-stream cycles are what it is for)
 #endif
 };
+
+// Layout-dependent accessors (see HX_SLIM above)
+#if HX_SLIM
+#define IX(c) (reinterpret_cast<ix_t *>(&L.term[0][0]) + 576 * (c))
+#define BAND_LANDING (reinterpret_cast<HxBandPrep *>(&L.term[1][0]))
+#define LANE_SINK (reinterpret_cast<float *>(&L.lucky[0][0][0]) + LANE)       // big_lucky's results are written after its terms
+#define MBLOG(x) hx_mblog16(L.mblog, (x))
+// 2^((g - 8) / 4) and 2^(-3 (g - 8) / 16) as the tables hold them: float(2^(r / 4)) x 2^q is exact, and so is the period-16 form
+// of the second (hx_host.cpp: slim_tables_ok)
+__device__ __forceinline__ float lk_gain(const float *g4, int g) { const int k = g - 8; return ldexpf(g4[k & 3], k >> 2); }
+__device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int k = g - 8; return ldexpf(ig16[k & 15], -3 * (k >> 4)); }
+#define LK_GAIN(g) lk_gain(L.gain4, (g))
+#define LK_IGAIN(g) lk_igain(L.igain16, (g))
+#else
+#define IX(c) (&L.ix[(c)][0])
+#define BAND_LANDING (&L.band_next)
+#define LANE_SINK (&L.dump[LANE])
+#define MBLOG(x) hx_mblog(L.mblog, (x))
+#define LK_GAIN(g) L.look_gain[(g)]
+#define LK_IGAIN(g) L.look_34igain[(g)]
+#endif
 
 #ifdef HX_PROFILE
 // (only the master wave's time is booked: the helper wave runs some of the same functions)
@@ -157,7 +240,20 @@ struct alignas(16) AllocLds {
 // Rarely taken paths are kept out of line, away from the hot code: the kernel's instructions do not fit
 // the instruction cache that the waves of a CU share (DESIGN.md, K6 in detail).
 #define HX_COLD __attribute__((noinline, cold))
-#define LANE ((int) threadIdx.x & 63)
+// The lane number as a value the compiler cannot see through, taken once per function (HX_LANE_DECL at its top; LANE is that
+// local).  As the pure threadIdx.x & 63 every predicate and LDS address derived from it - i < NB, LANE < 44, base + 4 * lane,
+// dozens of them after inlining - is loop-invariant, gets hoisted out of the frame loop and stays live over all of it: some
+// 130 scalar registers (lane predicates are register pairs) spilled into VGPR lanes, and at the 168-register build those VGPRs
+// and 27 more into scratch, reloaded at 61 places of the frame loop.  Recomputed where a function starts, they cost two
+// instructions there and die with the function.
+__device__ __forceinline__ int hx_lane_opaque()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+#define HX_LANE_DECL const int lane_ = hx_lane_opaque()
+#define LANE lane_
 #define WAVE ((int) threadIdx.x >> 6)
 // The workgroup is a single wavefront, and a wave's LDS operations execute in issue order, so an
 // LDS hand-over between lanes only needs the compiler to keep the accesses in program order.
@@ -193,7 +289,22 @@ __device__ __forceinline__ void glds16(const void *g, void *lds)
 }
 
 // x^(3/4): piecewise-linear mantissa fit x exponent table (reference pow34.c:132-154)
+#if HX_SLIM
+// (the exponent table 2^(3 (e - 127) / 4) as ldexp of the four mantissas 2^(r / 4); its ends are 0 and infinity)
+__device__ __forceinline__ float pow34(const AllocLds &L, float x)
+{
+    const unsigned u = hx_f2bits(x);
+    const float m = hx_bits2f((u & 0x7FFFFFu) | (127u << 23));
+    const unsigned seg = (u >> 19) & 15;
+    const int e = (int) ((u >> 23) & 255), k = 3 * (e - 127);
+    float ex = ldexpf(L.gain4[k & 3], k >> 2);
+    if (e == 0) ex = 0.0f;
+    if (e == 255) ex = hx_bits2f(0x7F800000u);
+    return (m * L.pow34_b[seg] + L.pow34_a[seg]) * ex;
+}
+#else
 __device__ __forceinline__ float pow34(const AllocLds &L, float x) { return hx_pow34(L.pow34_a, L.pow34_b, L.pow34_exp, x); }
+#endif
 
 __device__ __forceinline__ int logsubber(const AllocLds &L, int n1, int n2)
 {
@@ -278,6 +389,7 @@ struct SweepRegs { float x34[9], xr[9]; int bnd[9]; };
 
 __device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R, int ch)
 {
+    HX_LANE_DECL;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const int j = LANE + 64 * k;
@@ -295,6 +407,7 @@ __device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R, int 
 // evaluated get a meaningless term, which nobody reads - cheaper than predicating the store.
 __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int ch, int lo, int nl)
 {
+    HX_LANE_DECL;
 #pragma unroll
     for (int c3 = 0; c3 < 3; c3++) {
         if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
@@ -316,6 +429,7 @@ __device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int
 // path neither registers nor code.  (Bands that are not evaluated quantise to <= 0.)
 __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl)
 {
+    HX_LANE_DECL;
     if (LANE == 0) atomicAdd(L.big_counter, 1);
 #pragma unroll 1
     for (int c3 = 0; c3 < 3; c3++) {
@@ -353,6 +467,7 @@ __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl
 // x34max, logcbw = the band lane's constants, kept by the caller)
 __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int ch, int g, float ig_g, float gn_g, float x34max, int logcbw, int sbeg, int send, int nlines)
 {
+    HX_LANE_DECL;
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
     // and the line range that any evaluated band touches: the bands lie in lane order, so it runs from the first
     // evaluated band's start to the last one's end (two lane reads instead of two wave reductions)
@@ -379,7 +494,7 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
     int noise = 0;
     if (g >= 0) {
         const float sxx = band_sum(&L.term[ch][sbeg], send - sbeg, 0.0f);
-        noise = hx_mblog(L.mblog, 1.0e-12f + sxx) - logcbw;
+        noise = MBLOG(1.0e-12f + sxx) - logcbw;
     }
     SYNC();
     PROF_ACC(29);
@@ -390,6 +505,7 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
 // reference bitallo3.cpp:1069-1126
 __device__ void adjust_nt(AllocLds &L, const AllocPrm *p)
 {
+    HX_LANE_DECL;
     const int f = p->test1;
     if (f == 0) return;
     const int ch = LANE >> 5, i = LANE & 31;
@@ -418,6 +534,7 @@ struct BandIn { float xsxx, x34max; int n0, n0ms, gzero, maskmb; };     // band 
 
 __device__ __forceinline__ BandIn band_fetch(const HxBandPrep *bp)
 {
+    HX_LANE_DECL;
     const int ch = LANE >> 5, i = min(LANE & 31, NB - 1);
     BandIn b;
     b.xsxx = bp->xsxx[ch][i]; b.x34max = bp->x34max[ch][i]; b.n0 = bp->n0[ch][i]; b.n0ms = bp->n0ms[ch][i];
@@ -427,6 +544,7 @@ __device__ __forceinline__ BandIn band_fetch(const HxBandPrep *bp)
 
 __device__ void startup_prepped(AllocLds &L, const AllocPrm *p, int ms, const BandIn &in)
 {
+    HX_LANE_DECL;
     if (ms) {
         if (LANE == 0 && p->vbr_flag == 0 && L.call_count > 10 && (L.TargetBits - L.minTargetBits) < 100)
             L.MNR = min(L.MNR + 50, 2050);
@@ -471,13 +589,14 @@ __device__ void startup_prepped(AllocLds &L, const AllocPrm *p, int ms, const Ba
 // reference bitallo3.cpp:1130-1160
 __device__ void seek_initial(AllocLds &L, const AllocPrm *p)
 {
+    HX_LANE_DECL;
     const int ch = LANE >> 5, i = LANE & 31;
     if (i < p->nsf[ch]) {
         int na = L.NTadjust[ch][i];
         na = max(na, -400);
         na = min(na, 400);
         L.NTadjust[ch][i] = na;
-        float g4 = 0.017716950f * hx_mblog(L.mblog, L.x34max[ch][i]) + (88.411238f - 100.0f + 8.0f);
+        float g4 = 0.017716950f * MBLOG(L.x34max[ch][i]) + (88.411238f - 100.0f + 8.0f);
         float d = (1.00f / 110.5f) * (1800 - 8 * i - (L.Noise0[ch][i] - L.NT[ch][i] + na));
         float g = g4 + d;
         int gs = hx_round(g);
@@ -491,6 +610,7 @@ __device__ void seek_initial(AllocLds &L, const AllocPrm *p)
 // reference bitallo3.cpp:1164-1296: all bands of channel ch walk their gain step concurrently (lane = sfb)
 __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
 {
+    HX_LANE_DECL;
     const int i = LANE;
     const bool band = i < p->nsf[ch];
     // per-lane state machine: mode 0 = idle/done, 1 = first measurement, 2 = walking down, 3 = walking up.
@@ -517,7 +637,7 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
     const int ib = min(i, NB - 1);
     const float x34max = L.x34max[ch][ib];
     const int logcbw = L.logcbw[ib];
-    float ig_c = L.look_34igain[s & 127], gn_c = L.look_gain[s & 127];      // pair of the step to measure now
+    float ig_c = LK_IGAIN(s & 127), gn_c = LK_GAIN(s & 127);      // pair of the step to measure now
     float ig_dn = 0.0f, gn_dn = 0.0f, ig_up = 0.0f, gn_up = 0.0f;          // pairs of the steps below / above it
     SYNC();
     while (__any(mode != 0)) {
@@ -528,8 +648,8 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
         const int gcur = (mode == 0) ? -1 : (mode == 1 ? s : t);
         {   // requested now, used after this sweep
             const int gq = max(gcur, 0);
-            if (mode != 3) { ig_dn = L.look_34igain[max(gq - 1, 0)]; gn_dn = L.look_gain[max(gq - 1, 0)]; }
-            if (mode != 2) { ig_up = L.look_34igain[min(gq + 1, 127)]; gn_up = L.look_gain[min(gq + 1, 127)]; }
+            if (mode != 3) { ig_dn = LK_IGAIN(max(gq - 1, 0)); gn_dn = LK_GAIN(max(gq - 1, 0)); }
+            if (mode != 2) { ig_up = LK_IGAIN(min(gq + 1, 127)); gn_up = LK_GAIN(min(gq + 1, 127)); }
         }
         const int noise = noise_sweep(L, R, ch, gcur, ig_c, gn_c, x34max, logcbw, sbeg, send, nl);
         if (mode == 1) {
@@ -557,6 +677,7 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
 // both channels: channel 1's whole search on the helper wave
 __device__ void seek_actual(AllocLds &L, const AllocPrm *p)
 {
+    HX_LANE_DECL;
     const bool two = p->nbmax[1] > 0;
     if (two) HELPER_POST(HCMD_SEEK, 0);
     seek_actual_ch(L, p, 0);
@@ -577,6 +698,7 @@ __device__ __forceinline__ int half_or(int v) { return hx_half_or(v); }
 
 __device__ int scale_factors(AllocLds &L, const AllocPrm *p, int ms)
 {
+    HX_LANE_DECL;
     const int ch = LANE >> 5, i = LANE & 31;
     const bool band = i < p->nsf[ch];
     int gsf = 0, gz = 0, act = 0;
@@ -676,6 +798,7 @@ __device__ int scale_factors(AllocLds &L, const AllocPrm *p, int ms)
 template <int NQ>
 __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, float *tf, int w)
 {
+    HX_LANE_DECL;
     float sx34[NQ], sxr[NQ];
     int sg[NQ], ssd[NQ], stride[NQ];
     float *base[NQ];
@@ -688,7 +811,7 @@ __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, floa
         sxr[q] = L.xr[cc][j];
         sg[q] = max(L.geval[cc][L.band_of_line[j]], 0);
         ssd[q] = 2 * (1 + L.scale[cc]);
-        base[q] = ok ? &tf[t] : &L.dump[LANE];
+        base[q] = ok ? &tf[t] : LANE_SINK;
         stride[q] = ok ? 2 * nl : 0;
     }
     for (int c0 = 0; c0 < ncmax; c0 += 3) {
@@ -698,7 +821,7 @@ __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, floa
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const int g = min(sg[q] + (c0 + cu) * ssd[q], 127);
-                v[cu][q] = noise_term_fast(L, L.look_34igain[g], L.look_gain[g], sx34[q], sxr[q]);
+                v[cu][q] = noise_term_fast(L, LK_IGAIN(g), LK_GAIN(g), sx34[q], sxr[q]);
             }
 #pragma unroll
         for (int cu = 0; cu < 3; cu++)
@@ -713,6 +836,7 @@ __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, floa
 template <int NQ>
 __device__ __noinline__ void lucky_terms_big(AllocLds &L, int nl, int ncmax, float *tf, int w)
 {
+    HX_LANE_DECL;
     float sx34[NQ], sxr[NQ];
     int sg[NQ], ssd[NQ], stride[NQ];
     float *base[NQ];
@@ -725,7 +849,7 @@ __device__ __noinline__ void lucky_terms_big(AllocLds &L, int nl, int ncmax, flo
         sxr[q] = L.xr[cc][j];
         sg[q] = max(L.geval[cc][L.band_of_line[j]], 0);
         ssd[q] = 2 * (1 + L.scale[cc]);
-        base[q] = ok ? &tf[t] : &L.dump[LANE];
+        base[q] = ok ? &tf[t] : LANE_SINK;
         stride[q] = ok ? 2 * nl : 0;
     }
 #pragma unroll 1
@@ -736,8 +860,8 @@ __device__ __noinline__ void lucky_terms_big(AllocLds &L, int nl, int ncmax, flo
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const int g = min(sg[q] + c * ssd[q], 127);
-            const float ig = L.look_34igain[g];
-            gn[q] = L.look_gain[g];
+            const float ig = LK_IGAIN(g);
+            gn[q] = LK_GAIN(g);
             const float tmp = (ig * sx34[q] + (0.0f - 0.0946f));
             qx[q] = (int) (tmp + copysignf(0.5f, tmp));
             v[q] = noise_term_fast(L, ig, gn[q], sx34[q], sxr[q]);
@@ -766,6 +890,7 @@ __device__ __forceinline__ void lucky_dispatch(AllocLds &L, int nl, int ncmax, f
 // reference bitallo3.cpp:1348-1396
 __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 {
+    HX_LANE_DECL;
     // The candidates of a band (scalefactor s, s - sdelta, ... while G - s stays below gzero - 4)
     // do not depend on each other's result, so up to K of them are measured per pass for all
     // bands at once; the band lane then replays the reference's scan over the results in order.
@@ -798,13 +923,17 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
         }
         if (i < NB) { L.geval[ch][i] = (mode == 1) ? GG - s : -1; L.tmpn[ch][i] = nc; }
         // work list of the sums: one entry (c, ch, sfb) per candidate, compacted over the band lanes
-        int *list = &L.ix[0][0];                            // ix is not live before do_quant
+#if HX_SLIM
+        unsigned short *list = L.llist;
+#else
+        int *list = IX(0);                            // ix is not live before do_quant
+#endif
         const int incl = hx_wave_scan(nc), total = __builtin_amdgcn_readlane(incl, 63);
 #pragma unroll
         for (int c = 0; c < 6; c++) if (c < nc) list[incl - nc + c] = (c << 8) | (ch << 7) | i;
         SYNC();
         const int ncmax = hx_wave_max(nc);
-        const bool bslow = mode == 1 && noise_band_needs_pow(L.look_34igain[GG - s], L.x34max[ch][i]);
+        const bool bslow = mode == 1 && noise_band_needs_pow(LK_IGAIN(GG - s), L.x34max[ch][i]);
         PROF_ACC(23);
         // slots of 64 flattened lines: 3 or 4 (MPEG-2 band tables: 5), shared between the two waves
         const bool two = p->nchan == 2;
@@ -818,7 +947,7 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
         for (int u = LANE; u < total; u += 64) {
             const int e = list[u], c = e >> 8, cc = (e >> 7) & 1, b = e & 31;
             float sxx = band_sum(tf + c * 2 * nl + cc * nl + L.startBand[b], L.nBand[b], 0.0f);
-            L.lucky[c][cc][b] = hx_mblog(L.mblog, 1.0e-12f + sxx) - L.logcbw[b];
+            L.lucky[c][cc][b] = MBLOG(1.0e-12f + sxx) - L.logcbw[b];
         }
         SYNC();
         PROF_ACC(25);
@@ -847,7 +976,8 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
     // The work list lived in channel 0's line buffer (at most 6 x 26 entries).  The quantiser rewrites the coded lines
     // only: with a very low subband limit (E_CONTROL.nsb_limit = 4 at 48 kHz: 72 lines) the list's tail would stay behind as lines
     // (found by the round-3 sweep with nsb_limit in the draw).  Lines past the coded range are zero by contract.
-    for (int j = p->nbmax[0] + LANE; j < 6 * 26; j += 64) L.ix[0][j] = 0;
+    // (the low-footprint layout keeps the list elsewhere, and its quantiser writes every line)
+    if (!HX_SLIM) { for (int j = p->nbmax[0] + LANE; j < 6 * 26; j += 64) IX(0)[j] = 0; }
     SYNC();
 }
 
@@ -855,6 +985,7 @@ __device__ void big_lucky_noise(AllocLds &L, const AllocPrm *p)
 // quantise channel c's lines with the band gains published in L.gig, track the band maxima
 __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int opt, int c)
 {
+    HX_LANE_DECL;
     // all nine lines of a lane in one basic block: band -> igain -> rounding offset are dependent LDS reads, the nine
     // chains overlap; stores (and the band maxima) come after all loads
     const int nl = p->nbmax[c];
@@ -877,19 +1008,26 @@ __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int 
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const int j = LANE + 64 * k;
+#if HX_SLIM
+        // the line buffer held noise terms before: every line is written, zeros past the coded range
+        IX(c)[j] = (ix_t) ((j < nl) ? q[k] : 0);
+        if (j < nl && q[k] > 0) atomicMax(&L.ixmax[c][b[k]], q[k]);
+#else
         if (j < nl) {
-            L.ix[c][j] = q[k];
+            IX(c)[j] = q[k];
             if (q[k] > 0) atomicMax(&L.ixmax[c][b[k]], q[k]);
         }
+#endif
     }
 }
 
 __device__ void do_quant(AllocLds &L, const AllocPrm *p, int opt)
 {
+    HX_LANE_DECL;
     const int ch = LANE >> 5, i = LANE & 31;
     if (i < NB) {
         L.ixmax[ch][i] = (i < p->nsf[ch]) ? 0 : L.ixmax[ch][i];
-        L.gig[ch][i] = L.look_34igain[L.gsf[ch][i] & 127];     // the band's 1/gain^(3/4), read per line below
+        L.gig[ch][i] = LK_IGAIN(L.gsf[ch][i] & 127);     // the band's 1/gain^(3/4), read per line below
     }
     SYNC();
     // three lines per lane and chunk: band -> igain -> rounding offset are dependent LDS reads,
@@ -961,21 +1099,6 @@ __device__ __forceinline__ Cand candidates(const AllocLds &L, int rmax)
     return mk_cand(lo & 7, (lo >> 3) & 31, (lo >> 8) & 31, (lo >> 13) & 31, (lo >> 18) & 31, (int) (pk >> 23));
 }
 
-// coded length of one pair in table t: Huffman length + sign bits + linbits
-__device__ __forceinline__ int pair_len(const AllocLds &L, int t, int x, int y)
-{
-    int n;
-    if (t >= 16) {
-        int cx = x > 15 ? 15 : x, cy = y > 15 ? 15 : y, lin = L.huff_lin[t];
-        n = L.huff_len[L.huff_off[t] + cx * 16 + cy];
-        if (x >= 15) n += lin;
-        if (y >= 15) n += lin;
-    } else {
-        n = L.huff_len[L.huff_off[t] + x * L.huff_dim[t] + y];
-    }
-    return n + (x != 0) + (y != 0);
-}
-
 // table parameters packed into one word: code-table offset | row stride << 12 | linbits << 20
 // (tables >= 16 are 16 x 16 with escapes above 14; the smaller ones have no escapes)
 __device__ __forceinline__ int tab_pack(const AllocLds &L, int t) { return L.tabpk[t]; }
@@ -987,6 +1110,9 @@ __device__ __forceinline__ int pair_len_p(const AllocLds &L, int pk, int x, int 
     n += (x >= 15 ? lin : 0) + (y >= 15 ? lin : 0);
     return n + (x != 0) + (y != 0);
 }
+
+// coded length of one pair in table t: Huffman length + sign bits + linbits
+__device__ __forceinline__ int pair_len(const AllocLds &L, int t, int x, int y) { return pair_len_p(L, tab_pack(L, t), x, y); }
 
 // packed 16-bit length sums of one pair for the candidates of a region
 __device__ __forceinline__ void acc_pair(const AllocLds &L, const Cand &c, int x, int y, int &p01, int &p23)
@@ -1021,8 +1147,9 @@ __device__ __forceinline__ int region_max(const int *ixmax, int a, int b)
 
 __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
 {
+    HX_LANE_DECL;
     const int *ixmax = L.ixmax[ch];
-    const int *ix = L.ix[ch];
+    const ix_t *ix = IX(ch);
     const int bt = L.block_type;
     PROF_T0();
     int cb0, cb1, cb2, cb3;
@@ -1096,7 +1223,11 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
         const bool any4 = c0.n == 4 || c1.n == 4 || c2.n == 4;
         int2 xy[5];
 #pragma unroll
+#if HX_SLIM
+        for (int k = 0; k < 5; k++) { const unsigned w = reinterpret_cast<const unsigned *>(ix)[min(LANE + 64 * k, 287)]; xy[k] = make_int2((int) (w & 0xFFFFu), (int) (w >> 16)); }
+#else
         for (int k = 0; k < 5; k++) xy[k] = reinterpret_cast<const int2 *>(ix)[min(LANE + 64 * k, 287)];
+#endif
         int acc[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -1141,8 +1272,13 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int q = min(LANE + 64 * k, max(nquads - 1, 0));
+#if HX_SLIM
+            const uint2 w2 = *reinterpret_cast<const uint2 *>(ix + nbig + 4 * q);      // (nbig is even: 4-byte aligned)
+            qv[k][0] = make_int2((int) (w2.x & 0xFFFFu), (int) (w2.x >> 16)); qv[k][1] = make_int2((int) (w2.y & 0xFFFFu), (int) (w2.y >> 16));
+#else
             const int2 *v2 = reinterpret_cast<const int2 *>(ix + nbig + 4 * q);
             qv[k][0] = v2[0]; qv[k][1] = v2[1];
+#endif
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -1182,6 +1318,7 @@ __device__ int count_bits_ch(AllocLds &L, const AllocPrm *p, int ch, int ncb)
 
 __device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
 {
+    HX_LANE_DECL;
     PROF_CNT(22);
     // the channels are counted at the same time: channel 1 by the helper wave
     const bool two = p->nchan == 2;
@@ -1197,10 +1334,11 @@ __device__ int count_bits(AllocLds &L, const AllocPrm *p, const int *ncb)
 // zero21: clear the mid channel's entry of band 21 before counting (M/S granules, reference bitallo3.cpp:640-645).
 __device__ int quant_count_bits(AllocLds &L, const AllocPrm *p, int opt, int zero21, const int *ncb)
 {
+    HX_LANE_DECL;
     const int ch = LANE >> 5, i = LANE & 31;
     if (i < NB) {
         L.ixmax[ch][i] = (i < p->nsf[ch]) ? 0 : L.ixmax[ch][i];
-        L.gig[ch][i] = L.look_34igain[L.gsf[ch][i] & 127];
+        L.gig[ch][i] = LK_IGAIN(L.gsf[ch][i] & 127);
     }
     SYNC();
     PROF_CNT(22);

@@ -37,10 +37,12 @@ __global__ void k_pack_pre(const HxStream *st, unsigned char *out, long long out
 __global__ void k_order(const unsigned *dur, int *order, int S);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
 __global__ void k_alloc(AllocArgs a);
+__global__ void k_alloc_slim(AllocArgs a);
 __global__ void k_alloc_lsf(AllocArgs a);
 __global__ void k_alloc1(AllocArgs a);
 __global__ void k_alloc1_lsf(AllocArgs a);
 extern "C" int k_alloc_lds_bytes();
+extern "C" int k_alloc_slim_lds_bytes();
 extern "C" int k_alloc_lsf_lds_bytes();
 extern "C" int k_alloc1_lds_bytes();
 extern "C" int k_alloc1_lsf_lds_bytes();
@@ -91,6 +93,7 @@ struct hx_batch {
     bool any_dc = false;
     int nchan = 2;                      // channels of the PCM input, the same for every stream of the batch
     int lsf = 0;                        // 1: an MPEG-2 LSF batch (16 / 22.05 / 24 kHz): every 1152-sample block yields two frames
+    int slim = 0;                       // 1: the low-footprint stream walk k_alloc_slim (six streams per CU instead of four), chosen at create
     int alloc1 = 0;                     // 1: streams of the first-generation allocator (intensity stereo, dual channel): k_alloc1*
     int *d_eng = nullptr, *d_msbase = nullptr, *d_status = nullptr, *d_dbgmetric = nullptr;
     unsigned char *d_flg = nullptr, *d_bt = nullptr, *d_btprev = nullptr;
@@ -281,6 +284,20 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         const size_t dyn = b->alloc1 ? (b->lsf ? K6_LDS(k_alloc1_lsf) : K6_LDS(k_alloc1)) : (b->lsf ? K6_LDS(k_alloc_lsf) : K6_LDS(k_alloc));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 128, dyn) != hipSuccess || per_cu <= 0) per_cu = 4;
         b->resident = per_cu * prop.multiProcessorCount;
+        // Two builds of the MPEG-1 stream walk.  A batch that the chip holds at once (config 2: 1024 streams on 256 CUs x 4)
+        // runs the one written for 256 registers and 38 KB of LDS per stream; a larger one runs k_alloc_slim, whose streams
+        // take 168 registers and 26.5 KB, six to a CU: a stream is slower there, 1.5 x as many are in flight.
+        // HMP3AMD_K6 = fat | slim overrides the choice (tests run every case on both).
+        bool slim_ok = !b->alloc1 && !b->lsf;
+        for (int k = 0; k < b->ncls && slim_ok; k++) slim_ok = hx_slim_tables_ok(&b->params[k], &gt) != 0;
+        const char *e = getenv("HMP3AMD_K6");
+        const bool want = e ? (strcmp(e, "slim") == 0) : (S > b->resident);
+        if (e && strcmp(e, "slim") == 0 && !slim_ok && !b->alloc1 && !b->lsf) { set_err("HMP3AMD_K6=slim: the host's tables do not have the structure k_alloc_slim derives them from"); hx_batch_destroy(b); return nullptr; }
+        if (want && slim_ok) {
+            b->slim = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) k_alloc_slim, 128, K6_LDS(k_alloc_slim)) != hipSuccess || per_cu <= 0) per_cu = 6;
+            b->resident = per_cu * prop.multiProcessorCount;
+        }
     }
     if (b->any_dc) ALLOC(b->d_pcmf, sizeof(float) * S * max_frames * 1152 * b->nchan);
     HIPCHKN(hipMemcpy(b->d_prm, b->params.data(), sizeof(HxParams) * b->ncls, hipMemcpyHostToDevice));
@@ -613,6 +630,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     HIPCHK(hipEventRecord(e0, qa));
     if (b->alloc1) { if (b->lsf) LAUNCH_LDS(k_alloc1_lsf, dim3(S), dim3(128), K6_LDS(k_alloc1_lsf), qa, a); else LAUNCH_LDS(k_alloc1, dim3(S), dim3(128), K6_LDS(k_alloc1), qa, a); }
     else if (b->lsf) LAUNCH_LDS(k_alloc_lsf, dim3(S), dim3(128), K6_LDS(k_alloc_lsf), qa, a);
+    else if (b->slim) LAUNCH_LDS(k_alloc_slim, dim3(S), dim3(128), K6_LDS(k_alloc_slim), qa, a);
     else LAUNCH_LDS(k_alloc, dim3(S), dim3(128), K6_LDS(k_alloc), qa, a);
     HIPCHK(hipEventRecord(e1, qa));
     b->pending.push_back({e0, e1});
@@ -867,6 +885,11 @@ extern "C" int hx_batch_status(hx_batch *b)
     if (hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
 }
+
+// which build of the stream walk the batch runs: 0 = k_alloc (or the MPEG-2 / first-generation kernels), 1 = k_alloc_slim;
+// streams resident at once on the device
+extern "C" int hx_batch_k6_variant(const hx_batch *b) { return b ? b->slim : -1; }
+extern "C" int hx_batch_resident_streams(const hx_batch *b) { return b ? b->resident : -1; }
 
 // submits whose front end started late because its gate gave up waiting (see hx_batch_set_gate); synchronises
 extern "C" int hx_batch_gate_timeouts(hx_batch *b)

@@ -17,6 +17,13 @@ __device__ __forceinline__ int hx_mblog(const int *tab, float x)
     return tab[(u >> 15) & 255] + 301 * (int) (u >> 23);
 }
 
+// the same with the table as 16-bit values without its constant term (the allocator's low-footprint LDS layout)
+__device__ __forceinline__ int hx_mblog16(const unsigned short *tab, float x)
+{
+    unsigned u = hx_f2bits(x);
+    return (int) tab[(u >> 15) & 255] + 301 * (int) (u >> 23) - 38227;
+}
+
 // inverse (reference l3math.c:342-356)
 __device__ __forceinline__ float hx_mbexp(const float *lo, const float *hi, int x)
 {

@@ -610,3 +610,25 @@ void hx_stream_reset(const HxParams *p, int cls, HxStream *s)
         s->a1_ave_alpha = 40.0f;
     }
 }
+
+// The low-footprint stream walk (hx_alloc.hip, HX_SLIM) keeps 4 + 16 constants in place of the two 128-entry gain tables and
+// the 256-entry exponent table of x^(3/4): 2^((i - 8) / 4) has the mantissa of entry 8 + ((i - 8) & 3), 2^(-3 (i - 8) / 16) that
+// of entry 8 + ((i - 8) & 15), and scaling a float by a power of two is exact.  The tables come out of the host's pow(), so the
+// identity is checked on the tables a batch would use, bit for bit, before that kernel may be chosen.
+int hx_slim_tables_ok(const HxParams *p, const HxGlobalTabs *g)
+{
+    for (int i = 0; i < 128; i++) {
+        const int k = i - 8;
+        const float gn = ldexpf(p->look_gain[8 + (k & 3)], k >> 2), ig = ldexpf(p->look_34igain[8 + (k & 15)], -3 * (k >> 4));
+        if (memcmp(&gn, &p->look_gain[i], 4) != 0 || memcmp(&ig, &p->look_34igain[i], 4) != 0) return 0;
+    }
+    for (int e = 1; e < 255; e++) {
+        const int k = 3 * (e - 127);
+        const float ex = ldexpf(p->look_gain[8 + (k & 3)], k >> 2);
+        if (memcmp(&ex, &g->pow34_exp[e], 4) != 0) return 0;
+    }
+    if (g->pow34_exp[0] != 0.0f || !(g->pow34_exp[255] > 3.0e38f)) return 0;
+    for (int i = 0; i < 256; i++) if (g->mblog[i] + 38227 < 0 || g->mblog[i] + 38227 > 65535) return 0;
+    for (int i = 0; i < 84; i++) if (g->logsub[i] < -32768 || g->logsub[i] > 32767) return 0;
+    return 1;
+}

@@ -179,6 +179,12 @@ int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *
    It is a performance counter, not part of the health status. */
 int hx_batch_status(hx_batch *b);
 int hx_batch_gate_timeouts(hx_batch *b);
+/* Which build of the per-stream rate-loop kernel the batch runs (chosen at create from the batch size; the environment
+   variable HMP3AMD_K6 = fat | slim overrides): 0 = k_alloc, four streams per CU, 1 = k_alloc_slim, six per CU.  Both
+   restate the same reference code (bitallo3.cpp:484-3149) and produce the same bytes.  hx_batch_resident_streams: how many
+   of the batch's streams the device holds at once with that kernel. */
+int hx_batch_k6_variant(const hx_batch *b);
+int hx_batch_resident_streams(const hx_batch *b);
 /* identifies the build: a hash of the library's sources and code-generation flags (hmp3_amd/build.sh) */
 const char *hx_build_id(void);
 /* total frames / bytes emitted so far by stream i (synchronises) */

@@ -27,3 +27,19 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+# Every GPU test runs twice: on k_alloc (the stream walk written for four streams per CU) and on k_alloc_slim (its
+# low-footprint build, six per CU), forced through the library's environment switch; the bytes must not differ.
+# (MPEG-2 and first-generation-allocator batches have one kernel each and ignore the switch.)
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") is not None and "k6_build" in metafunc.fixturenames:
+        metafunc.parametrize("k6_build", ["fat", "slim"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def k6_build(request, monkeypatch):
+    which = getattr(request, "param", None)
+    if which is not None:
+        monkeypatch.setenv("HMP3AMD_K6", which)
+    yield which
