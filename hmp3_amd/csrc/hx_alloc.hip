@@ -252,7 +252,16 @@ __device__ __forceinline__ int hx_lane_opaque()
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+// (HX_OPAQUE_LANE: on for the 168-register build; the 256-register builds keep the plain value - there the hoisted values
+// stay in registers, and recomputing them costs the stream's chain 2 %)
+#ifndef HX_OPAQUE_LANE
+#define HX_OPAQUE_LANE HX_SLIM
+#endif
+#if HX_OPAQUE_LANE
 #define HX_LANE_DECL const int lane_ = hx_lane_opaque()
+#else
+#define HX_LANE_DECL const int lane_ = (int) threadIdx.x & 63
+#endif
 #define LANE lane_
 #define WAVE ((int) threadIdx.x >> 6)
 // The workgroup is a single wavefront, and a wave's LDS operations execute in issue order, so an
