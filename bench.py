@@ -286,12 +286,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed pass on the correlation-cycled signal set (config 2, one GPU)")
     ap.add_argument("--host-fed", type=int, default=-1, help="1 / 0: also time (or not) the workload fed from page-locked host memory through the pipelined host-buffer calls; default: config 2 only")
+    ap.add_argument("--other-configs", type=int, default=-1, help="1 / 0: also run BASELINE configs 3, 4 and 5 at full width for 4 timed steps each and append them as other_configs; default: with config 2 on one GPU at its own size")
     ap.add_argument("--no-pipeline", action="store_true", help="plain hx_batch_encode_s16_device calls instead of submit / wait")
     ap.add_argument("--gate", type=int, default=-1, help="hx_batch_set_gate percent (library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the barrier / max-time (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on GPU 0 (tests on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous, sharding and reporting only, no encode (CPU test of the multi-rank path)")
     args = ap.parse_args()
+    if args.other_configs < 0:
+        args.other_configs = 1 if (args.config == 2 and args.gpus == 1) else 0
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -306,15 +309,24 @@ def main():
     import numpy as np
     import torch
     from hmp3_amd import shard
-    wl = workload(args.config)
-    S = args.streams or wl["S"]
-    F = args.frames or wl["F"]
-    first, last = shard.shard_range(S * world, world, rank)     # weak scaling: S streams per GPU, contiguous block per rank
-    assert last - first == S
-    ncls = len(wl["classes"])
-    kws = [wl["classes"][(first + i) % ncls][0] for i in range(S)]
-    srs = [wl["classes"][(first + i) % ncls][1] for i in range(S)]
-    rhos = [wl["rho"][(first + i) % len(wl["rho"])] for i in range(S)]
+    def config_setup(cfg, S=0, F=0):
+        """one rank's share of a BASELINE configuration: weak scaling, S streams per GPU, a contiguous block per rank; the
+        stream classes and correlations cycle over the global stream index"""
+        wl = workload(cfg)
+        S = S or wl["S"]
+        F = F or wl["F"]
+        first, last = shard.shard_range(S * world, world, rank)
+        assert last - first == S
+        ncls = len(wl["classes"])
+        return dict(cfg=cfg, wl=wl, S=S, F=F, first=first, ncls=ncls,
+                    kws=[wl["classes"][(first + i) % ncls][0] for i in range(S)],
+                    srs=[wl["classes"][(first + i) % ncls][1] for i in range(S)],
+                    rhos=[wl["rho"][(first + i) % len(wl["rho"])] for i in range(S)])
+
+    main_c = config_setup(args.config, args.streams, args.frames)
+    wl, S, F, first, ncls, kws, srs, rhos = (main_c[k] for k in ("wl", "S", "F", "first", "ncls", "kws", "srs", "rhos"))
+    last = first + S
+    wl0, S0, F0, kws0, ncls0 = wl, S, F, kws, ncls
 
     dist = None
     if world > 1:
@@ -345,8 +357,12 @@ def main():
     if dist is not None:
         dist.init_process_group(args.backend)     # RCCL; used for the barrier and the max-over-ranks time only
 
-    def run(pcm, verify_n):
-        """warm-up + timed steps over one signal set with a fresh batch; returns measurements"""
+    def run(pcm, verify_n, c=None, steps=None, warmup=None):
+        """warm-up + timed steps over one signal set with a fresh batch; returns measurements
+        (c: another configuration's set-up from config_setup(), default = the line's own)"""
+        S, F, wl, kws, ncls = (c["S"], c["F"], c["wl"], c["kws"], c["ncls"]) if c else (S0, F0, wl0, kws0, ncls0)
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         ctl = api.default_control(**kws[0]) if ncls == 1 else [api.default_control(**k) for k in kws]
         batch = api.Batch(ctl, nstreams=S, max_frames=F, device=local)
         if args.gate >= 0:
@@ -377,12 +393,12 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         barrier()
         batch.alloc_kernel_ms()             # drop warm-up timings
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         barrier()
         dt = time.perf_counter() - t0
@@ -394,13 +410,17 @@ def main():
         m = {"dt": dt, "status": batch.status(), "out_total": int(nbytes.sum().item())}
         m["k_ms"], m["k_calls"] = batch.alloc_kernel_ms()
         try:
+            m["k6"] = {"kernel": ("k_alloc_slim" if batch.k6_variant() == 1 else None), "resident_streams": batch.resident_streams()}
+        except AttributeError:      # an older build of the library (HMP3AMD_LIB)
+            m["k6"] = None
+        try:
             m["gate_timeouts"] = batch.gate_timeouts()
         except AttributeError:      # an older build of the library (HMP3AMD_LIB)
             m["gate_timeouts"] = None
         if verify_n > 0:            # every rank checks streams of its own block
-            rs = np.random.RandomState(12345 + args.config + 1000 * rank)
+            rs = np.random.RandomState(12345 + (c["cfg"] if c else args.config) + 1000 * rank)
             ids = sorted(rs.choice(S, size=min(verify_n, S), replace=False).tolist())
-            ok, bad = verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, args.warmup + args.steps)
+            ok, bad = verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, warmup + steps)
             m["verified"], m["verify_bad"], m["verify_n"] = ok, bad, len(ids)
         batch.close()
         del out, nbytes, outs, nbs
@@ -457,11 +477,24 @@ def main():
         pcm = synth_batch_gpu(torch, np, S, F, srs, [RHO_CYCLE[i % 4] for i in range(S)], wl["bursts"], dev, first_stream=first)
         worst = run(pcm, 0)
     del pcm
+    # ---- the other BASELINE configurations at full width, a few steps each: reported beside `value`, never as it ----
+    others = []
+    if args.other_configs and not args.streams and not args.frames:
+        for cfg in (3, 4, 5):
+            if cfg == args.config:
+                continue
+            c = config_setup(cfg)
+            pcm = synth_batch_gpu(torch, np, c["S"], c["F"], c["srs"], c["rhos"], c["wl"]["bursts"], dev, first_stream=c["first"])
+            mo = run(pcm, min(args.verify, 8) if world == 1 else (2 if args.verify > 0 else 0), c=c, steps=4, warmup=2)
+            del pcm
+            torch.cuda.empty_cache()
+            others.append((c, mo))
 
     # ---- every rank's health in the line: status word (OR), gate time-outs (sum), streams verified (sum) ----
     # status bit 0..2 are failures (hmp3_amd.h); a gate time-out costs overlap only and is counted separately
     mine_bad = (m["status"] != 0) or (m.get("verified", 0) != m.get("verify_n", 0)) or (host_fed is not None and host_fed["kernel_status"] != 0) \
-        or (worst is not None and worst["status"] != 0)
+        or (worst is not None and worst["status"] != 0) \
+        or any(mo["status"] != 0 or mo.get("verified", 0) != mo.get("verify_n", 0) for _, mo in others)
     if os.environ.get("HMP3AMD_BENCH_FAULT_RANK") == str(rank):      # test hook: this rank reports a failure (tests/test_gpu_runtime.py)
         mine_bad = True
     vals = [m["status"] & 0x7FFFFFFF if m["status"] >= 0 else 0x40000000, m["gate_timeouts"] or 0, m.get("verified", 0), m.get("verify_n", 0), 1 if mine_bad else 0, 1]
@@ -497,6 +530,8 @@ def main():
         lib_id = api.build_id()
         stale = prof is not None and prof[0].get("build_id") != lib_id
         kernel = "k_alloc" if srs[0] >= 32000 else "k_alloc_lsf"
+        if m.get("k6") and m["k6"]["kernel"]:
+            kernel = m["k6"]["kernel"]          # the low-footprint build of the stream walk (picked by batch size)
         traffic = None
         valu = None
         if prof is not None and not stale:
@@ -550,6 +585,21 @@ def main():
             res["worst_case_value"] = round(S * F * args.steps / worst["dt"], 1)
             res["worst_case"] = {"signal": "inter-channel correlation cycled over {0.7, 0, 1, 0.3} by stream", "ms_per_step": round(worst["dt"] / args.steps * 1e3, 3),
                                  "kernel_ms": round(worst["k_ms"], 3), "kernel_status": worst["status"]}
+        if m.get("k6"):
+            res["roofline"]["resident_streams"] = m["k6"]["resident_streams"]
+        if others:
+            oc = []
+            for c, mo in others:
+                fr = c["S"] * c["F"]
+                opf = mo["out_total"] / float(fr)
+                ach_o = (bytes_in + opf) * fr / (mo["k_ms"] * 1e-3) / 1e9 if mo["k_ms"] > 0 else None
+                oc.append({"baseline_config": c["cfg"], "workload": c["wl"]["name"] % (c["S"], c["F"]), "value": round(fr * 4 * world / mo["dt"], 1), "unit": "frames/s",
+                           "steps": 4, "warmup": 2, "ms_per_step": round(mo["dt"] / 4 * 1e3, 3), "kernel_ms": round(mo["k_ms"], 3),
+                           "kernel_build": (mo["k6"]["kernel"] if mo.get("k6") and mo["k6"]["kernel"] else "k_alloc"),
+                           "resident_streams": mo["k6"]["resident_streams"] if mo.get("k6") else None,
+                           "roofline_frac": round(ach_o / HBM_PEAK_GBS, 6) if ach_o else None,
+                           "verified_streams": mo.get("verified"), "verify_checked": mo.get("verify_n"), "kernel_status": mo["status"]})
+            res["other_configs"] = oc
         if not args.no_cpu_baseline:
             # the reference CPU encoder on this box's host cores, in the same run (rank 0, after the timed regions; the
             # other ranks wait in the barrier below)

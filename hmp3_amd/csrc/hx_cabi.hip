@@ -956,6 +956,16 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
 
 // host-side table generation exposed for the CPU tests (no GPU needed): resolves `ec` and copies
 // the named table; returns bytes copied, 0 if the configuration is rejected, -1 for a bad name
+// 1 if the tables resolved for this control have the structure k_alloc_slim derives them from (hx_host.cpp: hx_slim_tables_ok)
+extern "C" int hx_debug_slim_tables_ok(const HX_E_CONTROL *ec)
+{
+    static HxParams p;
+    static HxGlobalTabs g;
+    if (!hx_resolve((const HxControl *) ec, &p)) return -1;
+    hx_global_tabs(&g);
+    return hx_slim_tables_ok(&p, &g);
+}
+
 extern "C" long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *name, void *dst, long long cap)
 {
     static HxParams p;

@@ -215,6 +215,10 @@ int hx_multi_status(hx_multi *m);
 /* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg"; copies at most cap bytes, returns bytes */
 long long hx_batch_debug_read(hx_batch *b, const char *name, void *dst, long long cap);
 void hx_batch_debug_enable(hx_batch *b, int on);
+/* 1 if the host tables of this control have the structure the low-footprint kernel derives them from (gain tables and
+   the x^(3/4) exponent table as ldexp of 4 / 16 constants, mB tables within 16 bits); hx_batch_create checks the same
+   before it picks that kernel.  -1 = configuration rejected.  Host only. */
+int hx_debug_slim_tables_ok(const HX_E_CONTROL *ec);
 /* host-side table generation for the CPU tests (no GPU): see hx_cabi.hip */
 long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *name, void *dst, long long cap);
 

@@ -371,3 +371,36 @@ def test_fuzz_cli_slice_against_the_reference_binary():
     end-of-input padding: 32-bit samples converted down by more than 1.14 never get the four calls of silence.)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "60", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_stream_walk_build_is_chosen_by_batch_size_and_both_give_the_same_bytes(monkeypatch):
+    """more streams than the chip holds at once -> k_alloc_slim (six streams per CU), otherwise k_alloc (four);
+    HMP3AMD_K6 overrides.  The same PCM through both builds: identical bytes, identical to the oracle."""
+    a = api()
+    kw = dict(bitrate=64)
+    monkeypatch.delenv("HMP3AMD_K6", raising=False)
+    small = a.Batch(a.default_control(**kw), nstreams=64, max_frames=4)
+    assert small.k6_variant() == 0 and small.resident_streams() % 4 == 0
+    cus = small.resident_streams() // 4
+    small.close()
+    S, F = 4 * cus + 8, 4
+    pcm = np.stack([synth.stream_pcm(900 + (i % 24), F, rho=RHOS[i % 4], bursts=True) for i in range(S)])
+    big = a.Batch(a.default_control(**kw), nstreams=S, max_frames=F)
+    assert big.k6_variant() == 1 and big.resident_streams() == 6 * cus
+    got_slim = big.encode_host(pcm)
+    assert big.status() == 0
+    big.close()
+    monkeypatch.setenv("HMP3AMD_K6", "fat")
+    fat = a.Batch(a.default_control(**kw), nstreams=S, max_frames=F)
+    assert fat.k6_variant() == 0 and fat.resident_streams() == 4 * cus
+    got_fat = fat.encode_host(pcm)
+    assert fat.status() == 0
+    fat.close()
+    assert got_fat == got_slim
+    for s_ in range(24):
+        assert got_slim[s_] == oracle_bytes(kw, pcm[s_], F), s_
+    # MPEG-2 batches have one kernel: the switch is ignored
+    monkeypatch.setenv("HMP3AMD_K6", "slim")
+    lsf = a.Batch(a.default_control(bitrate=32, samprate=22050), nstreams=8, max_frames=4)
+    assert lsf.k6_variant() == 0
+    lsf.close()

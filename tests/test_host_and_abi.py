@@ -123,3 +123,30 @@ def test_libm32_restatement_equals_this_machines_libm(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-DSTEP=997", "-o", exe, os.path.join(ROOT, "tools", "check_libm32.c"), "-lm"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_host_tables_have_the_structure_the_low_footprint_kernel_derives_them_from():
+    """k_alloc_slim keeps 4 + 16 constants in place of the 128-entry gain tables and the 256-entry x^(3/4) exponent
+    table (ldexp of the mantissa periods) and the mB tables as 16-bit values: the identity is checked on the host's
+    own tables, for every BASELINE configuration's stream classes, here and in hx_batch_create"""
+    from hmp3_amd import api
+    for kw in (dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(bitrate=64, samprate=32000),
+               dict(bitrate=64, samprate=48000), dict(bitrate=160), dict(bitrate=64, mode=3)):
+        assert api.lib().hx_debug_slim_tables_ok(C.byref(api.default_control(**kw))) == 1, kw
+    assert api.lib().hx_debug_slim_tables_ok(C.byref(api.default_control(bitrate=40))) == -1      # rejected configuration
+    # the same identities on the tables themselves, as the kernel evaluates them
+    eg = api.default_control(bitrate=64)
+
+    def tab(name, n, dt=np.float32):
+        a = np.zeros(n, dt)
+        assert api.lib().hx_debug_host_table(C.byref(eg), name.encode(), a.ctypes.data, a.nbytes) == a.nbytes
+        return a
+    gain, igain, pexp = tab("look_gain", 128), tab("look_34igain", 128), tab("pow34_exp", 256)
+    k = np.arange(128) - 8
+    assert np.array_equal(np.ldexp(gain[8 + (k & 3)], k >> 2).astype(np.float32).view(np.uint32), gain.view(np.uint32))
+    assert np.array_equal(np.ldexp(igain[8 + (k & 15)], -3 * (k >> 4)).astype(np.float32).view(np.uint32), igain.view(np.uint32))
+    e = 3 * (np.arange(1, 255) - 127)
+    assert np.array_equal(np.ldexp(gain[8 + (e & 3)], e >> 2).astype(np.float32).view(np.uint32), pexp[1:255].view(np.uint32))
+    assert pexp[0] == 0 and np.isinf(pexp[255])
+    mblog = tab("mblog", 256, np.int32)
+    assert mblog.min() + 38227 >= 0 and mblog.max() + 38227 <= 301

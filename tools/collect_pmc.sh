@@ -8,7 +8,7 @@ out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B="--steps 1 --warmup 0 --no-cpu-baseline --no-worst-case --host-fed 0 --verify 0 $*"
+B="--steps 1 --warmup 0 --no-cpu-baseline --no-worst-case --host-fed 0 --other-configs 0 --verify 0 $*"
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$name" -o p -- python3 bench.py $B > "$out/$name.log" 2>&1 || true; }
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY
 pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE

@@ -10,7 +10,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_$R
 mkdir -p $O
 for c in 2 3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$c -o t -- python3 bench.py --config $c --no-cpu-baseline --no-worst-case --host-fed 0 --verify 0 > $O/kt$c.log 2>&1 || true
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$c -o t -- python3 bench.py --config $c --no-cpu-baseline --no-worst-case --host-fed 0 --other-configs 0 --verify 0 > $O/kt$c.log 2>&1 || true
   f=$(find $O/kt$c -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && { head -1 "$f"; grep '^"k_' "$f"; } > $O/${R}_kernel_stats_bench_config$c.csv
   rm -rf $O/kt$c
@@ -22,5 +22,5 @@ cp $O/${R}_pmc_counters_*.json profiles/
 for c in 2 3 4 5; do
   python3 bench.py --config $c ${BENCH_EXTRA} 2> $O/bench_config$c.err | tail -1 > $O/${R}_bench_line_config$c.json || true
 done
-python3 bench.py --config 2 --no-pipeline --no-worst-case --host-fed 0 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_line_config2_no_pipeline.json || true
+python3 bench.py --config 2 --no-pipeline --no-worst-case --host-fed 0 --other-configs 0 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_line_config2_no_pipeline.json || true
 ls -la $O
