@@ -214,6 +214,11 @@ __device__ __forceinline__ float lk_gain(const float *g4, int g) { const int k =
 __device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int k = g - 8; return ldexpf(ig16[k & 15], -3 * (k >> 4)); }
 #define LK_GAIN(g) lk_gain(L.gain4, (g))
 #define LK_IGAIN(g) lk_igain(L.igain16, (g))
+// the same in two halves: the table read (asked for early), the scaling (where the value is needed)
+#define LK_GAIN_RAW(g) L.gain4[((g) - 8) & 3]
+#define LK_GAIN_FIN(raw, g) ldexpf((raw), ((g) - 8) >> 2)
+#define LK_IGAIN_RAW(g) L.igain16[((g) - 8) & 15]
+#define LK_IGAIN_FIN(raw, g) ldexpf((raw), -3 * (((g) - 8) >> 4))
 #else
 #define IX(c) (&L.ix[(c)][0])
 #define BAND_LANDING (&L.band_next)
@@ -221,6 +226,10 @@ __device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int 
 #define MBLOG(x) hx_mblog(L.mblog, (x))
 #define LK_GAIN(g) L.look_gain[(g)]
 #define LK_IGAIN(g) L.look_34igain[(g)]
+#define LK_GAIN_RAW(g) L.look_gain[(g)]
+#define LK_GAIN_FIN(raw, g) (raw)
+#define LK_IGAIN_RAW(g) L.look_34igain[(g)]
+#define LK_IGAIN_FIN(raw, g) (raw)
 #endif
 
 #ifdef HX_PROFILE
@@ -655,18 +664,17 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
         if (threadIdx.x == 64) L.prof[45] += 1;     // the helper wave's sweeps (channel 1)
 #endif
         const int gcur = (mode == 0) ? -1 : (mode == 1 ? s : t);
-        {   // requested now, used after this sweep
-            const int gq = max(gcur, 0);
-            if (mode != 3) { ig_dn = LK_IGAIN(max(gq - 1, 0)); gn_dn = LK_GAIN(max(gq - 1, 0)); }
-            if (mode != 2) { ig_up = LK_IGAIN(min(gq + 1, 127)); gn_up = LK_GAIN(min(gq + 1, 127)); }
-        }
+        // requested now, used after this sweep (low-footprint layout: the tables' mantissas now, their scaling then)
+        const int gdn = max(max(gcur, 0) - 1, 0), gup = min(max(gcur, 0) + 1, 127);
+        if (mode != 3) { ig_dn = LK_IGAIN_RAW(gdn); gn_dn = LK_GAIN_RAW(gdn); }
+        if (mode != 2) { ig_up = LK_IGAIN_RAW(gup); gn_up = LK_GAIN_RAW(gup); }
         const int noise = noise_sweep(L, R, ch, gcur, ig_c, gn_c, x34max, logcbw, sbeg, send, nl);
         if (mode == 1) {
             const int dn = noise - NTarget;
             ntadj += (dn >> 3);
             absmin = abs(dn); tnmin = noise; smin = s; iter = 0;
-            if (dn > 100) { t = s - 1; niter = min(t, 20); mode = (niter > 0) ? 2 : 0; ig_c = ig_dn; gn_c = gn_dn; }
-            else if (dn < -100) { t = s + 1; niter = 20; mode = 3; ig_c = ig_up; gn_c = gn_up; }
+            if (dn > 100) { t = s - 1; niter = min(t, 20); mode = (niter > 0) ? 2 : 0; ig_c = LK_IGAIN_FIN(ig_dn, gdn); gn_c = LK_GAIN_FIN(gn_dn, gdn); }
+            else if (dn < -100) { t = s + 1; niter = 20; mode = 3; ig_c = LK_IGAIN_FIN(ig_up, gup); gn_c = LK_GAIN_FIN(gn_up, gup); }
             else mode = 0;
         } else if (mode == 2 || mode == 3) {
             const int ad = abs(noise - NTarget);
@@ -674,8 +682,8 @@ __device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
             iter++;
             const bool stop = (mode == 2) ? (noise <= NTarget) : (noise >= NTarget);
             if (stop || iter >= niter) mode = 0;
-            else if (mode == 2) { t -= 1; ig_c = ig_dn; gn_c = gn_dn; }
-            else { t += 1; ig_c = ig_up; gn_c = gn_up; }
+            else if (mode == 2) { t -= 1; ig_c = LK_IGAIN_FIN(ig_dn, gdn); gn_c = LK_GAIN_FIN(gn_dn, gdn); }
+            else { t += 1; ig_c = LK_IGAIN_FIN(ig_up, gup); gn_c = LK_GAIN_FIN(gn_up, gup); }
         }
     }
     if (band) { L.gsf[ch][i] = smin; L.Noise[ch][i] = tnmin; L.NTadjust[ch][i] = ntadj; }
