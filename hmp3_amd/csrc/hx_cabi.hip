@@ -13,8 +13,7 @@
 #include "hx_src.h"
 
 // kernels (hx_front.hip / hx_alloc.hip)
-#define K1_GPB 14
-#define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
+// (K1_GPB / K1_THREADS, k_polyphase's tile and launch dimension: hx_types.h)
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
                             const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan, int *eng, int lsf);
 __global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S, int nchan);
@@ -704,16 +703,23 @@ extern "C" int hx_batch_submit_f32_device(hx_batch *b, const float *d_pcm, int n
 extern "C" void hx_batch_set_gate(hx_batch *b, int percent) { if (b) b->gate_percent = percent < 0 ? 0 : (percent > 100 ? 100 : percent); }
 
 // make `stream` wait for everything submitted so far
-extern "C" int hx_batch_wait(hx_batch *b, void *stream)
+static int batch_wait_pass(hx_batch *b, void *stream)
 {
-    if (!b) return -1;
-    if (!b->inflight) return 0;
     HIPCHK(hipSetDevice(b->device));
     if (flush_pack(b, -1) != 0) return -1;
     const int last = (int) ((b->nsubmit - 1) & 1);
     HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_front[last], 0));
     HIPCHK(hipStreamWaitEvent((hipStream_t) stream, b->ev_alloc[last], 0));
     return 0;
+}
+extern "C" int hx_batch_wait(hx_batch *b, void *stream)
+{
+    if (!b) return -1;
+    if (b->poisoned) { set_err("the batch is unusable after a failed device call: destroy it"); return -1; }
+    if (!b->inflight) return 0;
+    const int r = batch_wait_pass(b, stream);
+    if (r != 0) b->poisoned = true;         // (the deferred packing may be half enqueued)
+    return r;
 }
 
 // ---- pipelined host-buffer calls ----
@@ -729,9 +735,18 @@ extern "C" void *hx_pinned_alloc(long long bytes)
 }
 extern "C" void hx_pinned_free(void *p) { if (p) hipHostFree(p); }
 
+static int submit_host_pass(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes);
 static int submit_host(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
 {
     if (check_call(b, pcm, nframes, out, out_stride, out_bytes) != 0) return -1;
+    // like encode_core: a HIP call that fails once staging buffers, events or the call counter have been touched leaves the
+    // batch half updated; it refuses further calls instead of running on
+    const int r = submit_host_pass(b, pcm, is_f32, nframes, out, out_stride, out_bytes);
+    if (r != 0) b->poisoned = true;
+    return r;
+}
+static int submit_host_pass(hx_batch *b, const void *pcm, int is_f32, int nframes, unsigned char *out, long long out_stride, int *out_bytes)
+{
     HIPCHK(hipSetDevice(b->device));
     const long long pbytes = (long long) b->S * nframes * 1152 * b->nchan * (is_f32 ? sizeof(float) : sizeof(int16_t)), obytes = (long long) b->S * out_stride;
     if (!b->s_h2d) {
@@ -790,8 +805,12 @@ extern "C" int hx_batch_submit_f32_host(hx_batch *b, const float *pcm, int nfram
 extern "C" int hx_batch_wait_host(hx_batch *b)
 {
     if (!b) return -1;
-    HIPCHK(hipSetDevice(b->device));
-    if (b->s_d2h) { HIPCHK(hipStreamSynchronize(b->s_front)); HIPCHK(hipStreamSynchronize(b->s_d2h)); }
+    if (b->poisoned) { set_err("the batch is unusable after a failed device call: destroy it"); return -1; }
+    if (hipSetDevice(b->device) != hipSuccess || (b->s_d2h && (hipStreamSynchronize(b->s_front) != hipSuccess || hipStreamSynchronize(b->s_d2h) != hipSuccess))) {
+        set_err("HIP error while waiting for the host-buffer calls");
+        b->poisoned = true;
+        return -1;
+    }
     return 0;
 }
 
@@ -879,7 +898,7 @@ extern "C" int hx_batch_status(hx_batch *b)
     if (!b) return -1;
     if (b->poisoned) return -1;
     hipSetDevice(b->device);
-    if (b->s_pack) flush_pack(b, -1);
+    if (b->s_pack && flush_pack(b, -1) != 0) { b->poisoned = true; return -1; }     // (the last device-buffer submit's packing: it writes that submit's output buffers)
     hipDeviceSynchronize();
     // (a gate that gave up waiting costs overlap, not correctness: it is counted in hx_batch_gate_timeouts, not here)
     if (hipMemcpy(&v, b->d_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -23,8 +23,7 @@
 #endif
 
 #if HX_FRONT_PART & 1
-#define K1_GPB 14                       // granules per workgroup (252 of 256 lanes busy)
-#define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
+// (K1_GPB granules per workgroup, K1_THREADS lanes: hx_types.h, shared with the launch in hx_cabi.hip)
 
 #define K1_NS (480 + 576 * K1_GPB)      // staged samples
 #define K1_LDS (K1_NS + (K1_NS >> 5) + 1)
@@ -414,10 +413,16 @@ struct SpecTabs { int mblog[256]; float mbexp_lo[256], mbexp_hi[256]; };
 // Psychoacoustic model of a short granule's channel (reference emap.c:61-93, spdsmr.c:64-107): per-window partition
 // energies, then mask[w][sfb] = spread(2 sfb partitions); pre-echo control happens in the allocator.  x = the
 // channel's 576 lines (LDS); thr gets mask[12*w + sfb], etab zeros.  Short granules are rare: table reads from global memory.
-__device__ __noinline__ void psy_short(const float *x, const HxParams *p, float *etab_out, float *thr_out, float (*es)[64])
+// The function is out of line, so its pointers carry their address spaces: x and es are LDS, the rest global memory.  As
+// generic pointers they compiled to FLAT loads and stores, and the wave-local hand-overs here (FE_WAVE_SYNC: no s_waitcnt,
+// DS instructions execute in issue order) promise nothing about FLAT accesses that land in LDS.  tools/check_lds_flat.py
+// fails the build check if a FLAT instruction reappears in a front-end or packing function.
+#define HX_LDS __attribute__((address_space(3)))
+#define HX_GLB __attribute__((address_space(1)))
+__device__ __noinline__ void psy_short(const HX_LDS float *x, const HX_GLB HxParams *p, HX_GLB float *etab_out, HX_GLB float *thr_out, HX_LDS float (*es)[64])
 {
     const int lane = threadIdx.x & 63;
-    const HxPsyTab *ps = &p->psyS;
+    const HX_GLB HxPsyTab *ps = &p->psyS;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (lane < ps->npart_e) {
         int i0 = ps->pstart[lane], n = ps->nsum[lane];
@@ -725,8 +730,11 @@ __global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, cons
     }
     if (btype != 2) psy_long2(xl, p, T, pc, etab_out + sg * 128, thr_out + sg * 128, xtab_s[wv]);
     else {
-        psy_short(xl, p, etab_out + sg * 128, thr_out + sg * 128, es_s[wv]);
-        psy_short(xl + 576, p, etab_out + sg * 128 + 64, thr_out + sg * 128 + 64, es_s[wv]);
+        const HX_LDS float *xs = (const HX_LDS float *) xl;
+        HX_LDS float (*ess)[64] = (HX_LDS float (*)[64]) es_s[wv];
+        const HX_GLB HxParams *pg = (const HX_GLB HxParams *) p;
+        psy_short(xs, pg, (HX_GLB float *) (etab_out + sg * 128), (HX_GLB float *) (thr_out + sg * 128), ess);
+        psy_short(xs + 576, pg, (HX_GLB float *) (etab_out + sg * 128 + 64), (HX_GLB float *) (thr_out + sg * 128 + 64), ess);
     }
     msmetric_unit(xl, xl + 576, p, T.mblog, msbase + sg, btype == 2, sb_start, sb_n);
 }

@@ -178,6 +178,12 @@ struct alignas(16) HxFrameOut {
 };
 #define HX_SLOTS_EXTRA 40           // slots pending from earlier calls (the ring holds 32)
 
+// k_polyphase (hx_front.hip) and its launch (hx_cabi.hip): granules per workgroup (252 of 256 lanes busy: a lane is a time slot
+// of a granule) and the workgroup size that follows.  One definition: the kernel's launch bounds, its LDS staging stride and
+// register array are sized by the same numbers the host launches with.
+#define K1_GPB 14
+#define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
+
 // Arguments of the allocator kernels (k_alloc / k_alloc_lsf), filled by the host runtime.
 struct AllocArgs {
     HxStream *st;

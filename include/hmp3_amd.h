@@ -173,7 +173,9 @@ int hx_control_info(const HX_E_CONTROL *ec, HX_E_CONTROL *ec_out, HX_MPEG_HEAD *
 /* status bits accumulated by the kernels: 2 = main data overflow (the reference would assert
    there), 4 = the Huffman bits packed for a channel differ from the bits counted for it (an internal
    consistency check of the two-wave packer).  0 = healthy; -1 = no answer (the batch became unusable after a
-   failed device call, or the status could not be read).  Synchronises.
+   failed device call, or the status could not be read).  Synchronises - and, like hx_batch_wait, first enqueues the
+   packing that the last hx_batch_submit_*_device left for later: that writes the submit's output buffers, which must
+   therefore still be valid.
    hx_batch_gate_timeouts: how many pipelined submits started their front end late because the gate on the previous
    allocator launch gave up waiting (results are correct, overlap was lost; a loaded or profiled GPU can cause it).
    It is a performance counter, not part of the health status. */
