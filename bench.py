@@ -587,6 +587,10 @@ def main():
                                  "kernel_ms": round(worst["k_ms"], 3), "kernel_status": worst["status"]}
         if m.get("k6"):
             res["roofline"]["resident_streams"] = m["k6"]["resident_streams"]
+        try:        # which C library the checker on this box runs on (matters for first-generation-allocator streams only: hx_libm32.h)
+            res["host_libm"] = api.libm_report(1000)
+        except AttributeError:
+            pass
         if others:
             oc = []
             for c, mo in others:

@@ -51,7 +51,7 @@ EXPORTS = [
     "hx_batch_gate_timeouts", "hx_enc_out_stats", "hx_multi_create", "hx_multi_destroy", "hx_multi_ndevices", "hx_multi_nstreams", "hx_multi_shard", "hx_multi_batch",
     "hx_multi_out_stride", "hx_multi_encode_s16_host", "hx_multi_encode_f32_host", "hx_multi_encode_f32_host_stats", "hx_multi_status",
     "hx_build_id", "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
-    "hx_batch_k6_variant", "hx_batch_resident_streams", "hx_debug_slim_tables_ok",
+    "hx_batch_k6_variant", "hx_batch_resident_streams", "hx_debug_slim_tables_ok", "hx_libc_version", "hx_libm_spot_check",
 ]
 
 _lib = None
@@ -167,6 +167,14 @@ def default_control(**kw):
     if kw.get("bitrate", -1) > 0 and "vbr_flag" not in kw:
         ec.vbr_flag = 0
     return ec
+
+
+def libm_report(points=1000):
+    """the host's C library and whether its logf / log10f agree with the restatement the first-generation allocator's
+    kernels use (hx_libm32.h = glibc 2.35): {"glibc": "2.35", "points": 1000, "mismatches": 0}"""
+    L = lib()
+    L.hx_libc_version.restype = C.c_char_p
+    return {"glibc": L.hx_libc_version().decode(), "points": points, "mismatches": int(L.hx_libm_spot_check(points))}
 
 
 def build_id():

@@ -975,6 +975,9 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
 
 // host-side table generation exposed for the CPU tests (no GPU needed): resolves `ec` and copies
 // the named table; returns bytes copied, 0 if the configuration is rejected, -1 for a bad name
+extern "C" const char *hx_libc_version(void) { return hx_host_libc_version(); }
+extern "C" int hx_libm_spot_check(int n) { return hx_libm32_spot_check(n); }
+
 // 1 if the tables resolved for this control have the structure k_alloc_slim derives them from (hx_host.cpp: hx_slim_tables_ok)
 extern "C" int hx_debug_slim_tables_ok(const HX_E_CONTROL *ec)
 {

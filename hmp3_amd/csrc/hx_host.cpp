@@ -632,3 +632,27 @@ int hx_slim_tables_ok(const HxParams *p, const HxGlobalTabs *g)
     for (int i = 0; i < 84; i++) if (g->logsub[i] < -32768 || g->logsub[i] > 32767) return 0;
     return 1;
 }
+
+// ---- which libm the host has, against the one the first-generation allocator's kernels restate (hx_libm32.h) ----
+// The reference's bitallo1.cpp calls libm's logf / log10f, which are not correctly rounded: its output depends on the libm it
+// is linked with, and the kernels agree with glibc 2.35's.  The oracle on a box calls that box's libm; where the two differ a
+// parity test of those streams would compare two different references.  hx_host_libc_version: gnu_get_libc_version();
+// hx_libm32_spot_check: how many of n arguments spread over the positive normal floats give another logf or log10f here.
+#include <gnu/libc-version.h>
+#define HX_HD static inline
+#include "hx_libm32.h"
+const char *hx_host_libc_version(void) { return gnu_get_libc_version(); }
+int hx_libm32_spot_check(int n)
+{
+    int bad = 0;
+    if (n < 1) n = 1;
+    const unsigned long long span = 0x7f800000ull - 0x00800000ull;
+    for (int i = 0; i < n; i++) {
+        // a stride co-prime with the span walks exponents and mantissas alike
+        const uint32_t u = (uint32_t) (0x00800000ull + ((unsigned long long) i * 2654435761ull + 12345ull) % span);
+        const float x = hx_u2f(u);
+        volatile float a = logf(x), c = log10f(x);
+        if (hx_f2u(a) != hx_f2u(hx_logf(x)) || hx_f2u(c) != hx_f2u(hx_log10f(x))) bad++;
+    }
+    return bad;
+}

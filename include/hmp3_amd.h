@@ -217,6 +217,12 @@ int hx_multi_status(hx_multi *m);
 /* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg"; copies at most cap bytes, returns bytes */
 long long hx_batch_debug_read(hx_batch *b, const char *name, void *dst, long long cap);
 void hx_batch_debug_enable(hx_batch *b, int on);
+/* The first-generation allocator (intensity stereo, dual channel; reference bitallo1.cpp) calls libm's logf / log10f, which
+   are not correctly rounded: what the reference encodes depends on the C library it is linked with.  The kernels restate
+   glibc 2.35's (hmp3_amd/csrc/hx_libm32.h).  hx_libc_version: the host's C library; hx_libm_spot_check: how many of n
+   sample arguments the host's logf / log10f treat differently (0: a reference built on this host and the kernels agree). */
+const char *hx_libc_version(void);
+int hx_libm_spot_check(int n);
 /* 1 if the host tables of this control have the structure the low-footprint kernel derives them from (gain tables and
    the x^(3/4) exponent table as ldexp of 4 / 16 constants, mB tables within 16 bits); hx_batch_create checks the same
    before it picks that kernel.  -1 = configuration rejected.  Host only. */

@@ -43,3 +43,15 @@ def k6_build(request, monkeypatch):
     if which is not None:
         monkeypatch.setenv("HMP3AMD_K6", which)
     yield which
+
+
+def skip_unless_host_libm_is_the_restated_one():
+    """Streams of the first-generation allocator go through libm's logf / log10f in the reference (bitallo1.cpp is C++), which
+    are not correctly rounded; the kernels restate glibc 2.35's (hmp3_amd/csrc/hx_libm32.h) and the oracle calls this box's.
+    Where the two differ, an oracle comparison of those streams compares two references: skipped with the reason, not failed
+    (the committed golden streams, made on glibc 2.35, still pin the kernels there)."""
+    from hmp3_amd import api
+    rep = api.libm_report(1000)
+    if rep["mismatches"]:
+        pytest.skip("host glibc %s: logf / log10f differ from the glibc 2.35 restatement on %d of %d sample arguments; "
+                    "the oracle on this box is not the reference the kernels follow for first-generation-allocator streams" % (rep["glibc"], rep["mismatches"], rep["points"]))

@@ -12,6 +12,7 @@ import pytest
 
 from oracle import oracle as O
 from hmp3_amd import synth
+from conftest import skip_unless_host_libm_is_the_restated_one
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -137,6 +138,7 @@ def test_negative_scalefactors_go_through_the_unmasked_bit_writer(kw, seed, rho,
     """The first-generation allocator leaves an empty band's scalefactor at 0 - pretab when pre-emphasis is on (reference
     bitallo1.cpp:547-586); the reference's bit writer ORs the negative value into its buffer unmasked, which sets bits
     written just before it.  k_pack replays the writer's flush state to put the same stray bits in (hx_pack.hip)."""
+    skip_unless_host_libm_is_the_restated_one()
     pcm = synth.stream_pcm(seed, F, sr=kw["samprate"], rho=rho, bursts=bursts)
     pcm = (pcm.astype(np.float64) * 0.02).astype(np.int16)[None]
     b = api().Batch(api().default_control(**kw), nstreams=1, max_frames=F)
@@ -296,6 +298,7 @@ A1 = {
 @pytest.mark.parametrize("name", list(A1))
 def test_intensity_stereo_and_dual_channel_byte_identical_to_oracle(name):
     """the kernels k_alloc1 / k_alloc1_lsf (hx_alloc1.inc): 8 streams of differing channel correlation, ragged calls"""
+    skip_unless_host_libm_is_the_restated_one()
     kw, sr = A1[name]
     S, F = 8, 40
     pcm = np.stack([synth.stream_pcm(5200 + i, F, sr=sr, rho=RHOS[i % 4], bursts=(i % 2 == 0)) for i in range(S)])
@@ -316,6 +319,7 @@ def test_intensity_stereo_and_dual_channel_byte_identical_to_oracle(name):
 def test_intensity_stereo_stress_signals():
     """full-scale noise, a pure tone on both channels, silence, near-silence, anti-phase tone: the allocator's bit
     seek in both directions, silent channels, intensity positions at the extremes"""
+    skip_unless_host_libm_is_the_restated_one()
     F = 24
     n = F * 1152
     rng = np.random.default_rng(99)

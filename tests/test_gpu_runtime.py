@@ -266,6 +266,9 @@ def test_submit_path_for_every_stream_type(kw, nch):
 def test_fuzz_parity_slice(args):
     """fixed-seed slices of tools/fuzz_parity.py (the sweep that found the round-2 bit-writer defect): random controls x
     random and extreme signals in random-sized calls, GPU against the oracle"""
+    if "--a1" in args:
+        from conftest import skip_unless_host_libm_is_the_restated_one
+        skip_unless_host_libm_is_the_restated_one()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
@@ -404,3 +407,12 @@ def test_stream_walk_build_is_chosen_by_batch_size_and_both_give_the_same_bytes(
     lsf = a.Batch(a.default_control(bitrate=32, samprate=22050), nstreams=8, max_frames=4)
     assert lsf.k6_variant() == 0
     lsf.close()
+
+
+def test_soak_slice_six_thousand_frames_in_calls_of_1_to_64():
+    """a slice of tools/soak.py in the suite: CBR-128 and VBR-50 (block switching), 2 streams each (one with bursts), 6000
+    frames = 2.6 minutes of audio per stream through calls of 1 .. 64 frames on one batch object, against the oracle"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "6000", "2", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert out.count(" ok") == 2 and "6000 frames x 2 streams" in out

@@ -1,5 +1,6 @@
-"""Long continuous streams: python tools/soak.py [frames]  - a few configurations x 6 streams x `frames` frames (default 20000)
-through calls of random length on one batch object, compared byte for byte with the oracle.  Exit code 1 on a difference."""
+"""Long continuous streams: python tools/soak.py [frames] [cases] [streams]  - the first `cases` of six configurations (default
+all) x `streams` streams (default 6) x `frames` frames (default 20000) through calls of 1 .. 64 frames on one batch object,
+compared byte for byte with the oracle.  Exit code 1 on a difference.  (tests/test_gpu_runtime.py runs a slice: 6000 2 2)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,12 +10,14 @@ from oracle import oracle as O
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 CASES = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(samprate=22050, bitrate=32),
          dict(bitrate=64, mode=3), dict(samprate=16000, mode=2, bitrate=16)]
+CASES = CASES[:int(sys.argv[2])] if len(sys.argv) > 2 else CASES
+NS = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 bad = 0
 rs = np.random.RandomState(7)
 for kw in CASES:
     sr = kw.get("samprate", 44100)
     mono = kw.get("mode") == 3
-    S, CH = 6, 250                                  # frames per synthesised piece
+    S, CH = NS, 250                                 # frames per synthesised piece
     b = api.Batch(api.default_control(**kw), nstreams=S, max_frames=64)
     encs = [O.OracleEncoder(O.default_control(**kw)) for _ in range(S)]
     ok = True
