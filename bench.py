@@ -340,9 +340,19 @@ def main():
             dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         else:
             t = torch.tensor([1.0]); seen = torch.tensor([S])
+        # every rank's block as it would encode it: global stream range, and the stream classes / correlations at both ends
+        # (they cycle over the GLOBAL stream index, so they continue across the rank boundaries)
+        cls_of = [wl["classes"].index((kws[i], srs[i])) for i in list(range(min(6, S))) + list(range(max(S - 6, 0), S))]
+        mine = {"rank": rank, "first": first, "count": S, "cls_head": cls_of[:min(6, S)], "cls_tail": cls_of[-min(6, S):],
+                "rho_head": rhos[:6], "rho_tail": rhos[-6:], "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+        blocks = [mine]
+        if dist is not None:
+            blocks = [None] * world
+            dist.all_gather_object(blocks, mine)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int((seen > 0).sum()), "streams_total": int(seen.sum()),
-                              "max_time_token": float(t.item()), "config": {"workload": wl["name"] % (S, F)}}), flush=True)
+                              "max_time_token": float(t.item()), "blocks": blocks, "nclasses": ncls, "rho_cycle": wl["rho"],
+                              "config": {"workload": wl["name"] % (S, F), "baseline_config": args.config}}), flush=True)
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
@@ -354,6 +364,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # Host placement: this rank's thread - and with it the page-locked buffers it allocates (first touch) and the copies it
+    # submits - on the NUMA node its GPU hangs on.  At 8 GPUs x 49 GB/s of PCM the host-fed path is a host-memory-bandwidth
+    # problem; it is decided by which socket the buffers are on.  Best effort (no sysfs entry / one node: nothing changes).
+    cpus_before = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    try:
+        placement = {"rank": rank, "device": local, "numa_node": api.device_numa_node(local), "cpus_bound": api.bind_thread_to_device(local)}
+    except AttributeError:      # an older build of the library (HMP3AMD_LIB)
+        placement = {"rank": rank, "device": local, "numa_node": None, "cpus_bound": 0}
+    placement["cpus_allowed"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     if dist is not None:
         dist.init_process_group(args.backend)     # RCCL; used for the barrier and the max-over-ranks time only
 
@@ -451,6 +470,7 @@ def main():
         t0 = time.perf_counter()
         go(steps_h)
         dt = time.perf_counter() - t0
+        placement["host_fed_ms_per_step"] = round(dt / steps_h * 1e3, 3)       # this rank's own time (the line's value uses the slowest rank's)
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -507,6 +527,11 @@ def main():
         dist.all_gather(lst, t)
         per_rank = [x.cpu().tolist()[:6] for x in lst]
         k_ms_all = [x.cpu().tolist()[6] / 1000.0 for x in lst]
+    placements = [placement]
+    if dist is not None:
+        pl = [None] * world
+        dist.all_gather_object(pl, placement)
+        placements = pl
     status_or = 0
     for v in per_rank:
         status_or |= v[0]
@@ -604,7 +629,10 @@ def main():
                            "roofline_frac": round(ach_o / HBM_PEAK_GBS, 6) if ach_o else None,
                            "verified_streams": mo.get("verified"), "verify_checked": mo.get("verify_n"), "kernel_status": mo["status"]})
             res["other_configs"] = oc
+        res["host_placement"] = placements      # per rank: device, its NUMA node, CPUs the rank was bound to, its own host-fed step time
         if not args.no_cpu_baseline:
+            if cpus_before:
+                os.sched_setaffinity(0, cpus_before)        # the CPU baseline runs on every usable core, not on this GPU's socket only
             # the reference CPU encoder on this box's host cores, in the same run (rank 0, after the timed regions; the
             # other ranks wait in the barrier below)
             res["cpu_baseline"] = cpu_baseline(wl)

@@ -1248,6 +1248,74 @@ extern "C" void hx_enc_info_string(hx_enc *e, char *s)
 // blocks, one hx_batch per device, and every call runs one host thread per device on its block of the
 // caller's buffers.  Streams are independent, so nothing is exchanged between the devices.
 #include <thread>
+#include <sched.h>
+#include <unistd.h>
+
+// ---- host placement: the NUMA node of a device, and threads / page-locked buffers next to it ----
+// A host-fed GPU takes 49 GB/s of PCM over PCIe (bench.py host_fed); eight of them read 394 GB/s of host memory.  That only
+// works out of the memory of the socket the GPU hangs on: a rank (or a dispatcher thread) binds itself to the CPUs of its
+// device's NUMA node before it allocates its page-locked buffers (first touch puts the pages there) and stays there for its
+// copies' submission.  Everything here is best effort: no sysfs entry, one node, or a CPU set that the cgroup does not allow
+// leaves the thread where it was and reports -1 / 0.
+static int read_int_file(const char *path, int *v)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    const int ok = fscanf(f, "%d", v) == 1;
+    fclose(f);
+    return ok ? 0 : -1;
+}
+
+// NUMA node of HIP device `device` (-1: unknown / not a NUMA machine), from its PCI address in sysfs
+extern "C" int hx_device_numa_node(int device)
+{
+    char bus[64] = {0}, path[256];
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return -1;
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char) (*c - 'A' + 'a');      // sysfs spells the address in lower case
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    int node = -1;
+    if (read_int_file(path, &node) != 0) return -1;
+    return node;
+}
+
+// the CPUs of a node that this process may use: parses /sys/devices/system/node/node<N>/cpulist ("0-15,128-143")
+static int node_cpus_allowed(int node, cpu_set_t *out)
+{
+    char path[128], buf[4096];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!got) return 0;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+    CPU_ZERO(out);
+    int n = 0;
+    for (char *p = buf; *p;) {
+        char *e;
+        long a = strtol(p, &e, 10), z = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; z = strtol(p, &e, 10); }
+        for (long c = a; c <= z && c < CPU_SETSIZE; c++) if (CPU_ISSET((int) c, &allowed)) { CPU_SET((int) c, out); n++; }
+        p = (*e == ',') ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    return n;
+}
+
+// bind the calling thread to the allowed CPUs of `device`'s NUMA node; returns how many CPUs that is (0: left as it was)
+extern "C" int hx_bind_thread_to_device(int device)
+{
+    const int node = hx_device_numa_node(device);
+    if (node < 0) return 0;
+    cpu_set_t set;
+    const int n = node_cpus_allowed(node, &set);
+    if (n <= 0) return 0;
+    return sched_setaffinity(0, sizeof(set), &set) == 0 ? n : 0;
+}
+
 struct hx_multi {
     std::vector<hx_batch *> part;
     std::vector<int> first, count, device;
@@ -1313,6 +1381,7 @@ static int multi_call(hx_multi *m, int kind, const void *pcm, int nframes, unsig
     std::vector<std::thread> th;
     for (size_t k = 0; k < n; k++)
         th.emplace_back([&, k]() {
+            hx_bind_thread_to_device(m->device[k]);     // this device's copies are issued from its own socket (best effort)
             const long long f = m->first[k];
             const char *p = (const char *) pcm + (size_t) f * nframes * 1152 * m->nchan * esz;
             unsigned char *o = out + f * out_stride;

@@ -195,6 +195,14 @@ HX_INT_PAIR hx_batch_frames_bytes(hx_batch *b, int stream_index);
    milliseconds, measured with HIP events on the launch stream; also returns the call count */
 float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls);
 
+/* ---- host placement (no reference equivalent): a host-fed GPU reads ~50 GB/s of PCM over PCIe, so its page-locked
+   buffers and the threads that submit its copies belong on the NUMA node the device hangs on.
+   hx_device_numa_node: that node from sysfs (-1 = unknown or not a NUMA machine).  hx_bind_thread_to_device: restricts the
+   calling thread to the CPUs of that node which the process may use and returns their number (0 = nothing changed); call it
+   before hx_pinned_alloc so that first touch places the pages there.  hx_multi_* binds its per-device threads itself. */
+int hx_device_numa_node(int device);
+int hx_bind_thread_to_device(int device);
+
 /* ---- several GPUs of one node behind one handle (no reference equivalent) ----
    nstreams independent streams in contiguous blocks over ndev devices (devices[0..ndev), or devices
    0..ndev-1 when devices is NULL; ndev <= 0: every device present), block sizes differing by at most one;

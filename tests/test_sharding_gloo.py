@@ -83,3 +83,34 @@ def test_bench_rejects_world_size_that_differs_from_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.parametrize("cfg", [4, 5])
+def test_eight_ranks_take_eight_disjoint_blocks_and_the_class_cycles_run_on_across_them(cfg):
+    """world 8 on gloo, dry run: BASELINE config 4 (32768 streams = 8 x 4096) and config 5 (8 x 4096, three sample rates by
+    stream mod 3, correlation by stream mod 4).  Every rank reports its block; the blocks tile the global stream range in
+    rank order, and a stream's class and correlation follow from its GLOBAL index, so the cycles continue across the rank
+    boundaries (4096 is not a multiple of 3: a rank's first stream is not class 0)."""
+    rc, line, err = _run_bench(["--gpus", "8", "--dry-run", "--backend", "gloo", "--config", str(cfg)], timeout=900)
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["streams_total"] == 8 * 4096
+    assert line["max_time_token"] == 8.0            # max over ranks of (1 + rank)
+    blocks = sorted(line["blocks"], key=lambda b: b["rank"])
+    assert [b["rank"] for b in blocks] == list(range(8))
+    ncls, rho = line["nclasses"], line["rho_cycle"]
+    assert ncls == (3 if cfg == 5 else 1) and len(rho) == (4 if cfg == 5 else 1)
+    nxt = 0
+    for b in blocks:
+        assert b["first"] == nxt and b["count"] == 4096         # contiguous, disjoint, in rank order
+        for k in range(6):
+            g = b["first"] + k
+            assert b["cls_head"][k] == g % ncls and b["rho_head"][k] == rho[g % len(rho)]
+            g = b["first"] + b["count"] - 6 + k
+            assert b["cls_tail"][k] == g % ncls and b["rho_tail"][k] == rho[g % len(rho)]
+        nxt += b["count"]
+    assert nxt == 32768
+    if cfg == 5:
+        assert [b["cls_head"][0] for b in blocks] == [(4096 * r) % 3 for r in range(8)]      # 0, 1, 2, 0, ...: not reset per rank
