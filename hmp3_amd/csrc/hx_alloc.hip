@@ -1027,8 +1027,10 @@ __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int 
         const int j = LANE + 64 * k;
 #if HX_SLIM
         // the line buffer held noise terms before: every line is written, zeros past the coded range
-        IX(c)[j] = (ix_t) ((j < nl) ? q[k] : 0);
-        if (j < nl && q[k] > 0) atomicMax(&L.ixmax[c][b[k]], q[k]);
+        // (one value, one unconditional store: written as two conditions the compiler made two exec-masked paths per line)
+        const int qq = (j < nl) ? q[k] : 0;
+        IX(c)[j] = (ix_t) qq;
+        if (qq > 0) atomicMax(&L.ixmax[c][b[k]], qq);
 #else
         if (j < nl) {
             IX(c)[j] = q[k];
