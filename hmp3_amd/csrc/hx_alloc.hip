@@ -626,7 +626,15 @@ __device__ void seek_initial(AllocLds &L, const AllocPrm *p)
 }
 
 // reference bitallo3.cpp:1164-1296: all bands of channel ch walk their gain step concurrently (lane = sfb)
-__device__ void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
+#ifndef HX_SEEK_FORCEINLINE
+#define HX_SEEK_FORCEINLINE 0
+#endif
+#if HX_SEEK_FORCEINLINE
+#define HX_SEEK_INLINE __device__ __forceinline__
+#else
+#define HX_SEEK_INLINE __device__
+#endif
+HX_SEEK_INLINE void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
 {
     HX_LANE_DECL;
     const int i = LANE;

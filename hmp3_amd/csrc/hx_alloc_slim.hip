@@ -3,4 +3,5 @@
 // the chip holds at once (hx_cabi.hip picks it by batch size); kernel k_alloc_slim.
 #define HX_SLIM 1
 #define HX_WAVES 3
+#define HX_SEEK_FORCEINLINE 1     // the gain search inlined at its three call sites (as a call it saved and restored 54 registers per lane each time)
 #include "hx_alloc.hip"
