@@ -26,9 +26,9 @@ __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm,
 __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf, int nchan);
 __global__ void k_msscan(HxStream *st, const HxParams *prm, const int *msbase, const unsigned char *bt, unsigned char *msflag, int *msdec,
                          const float *thr, float *thrprev, int NG, int lsf);
-__global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned char *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
+__global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
                        const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG, long long nunits);
-__global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned char *sgn, const HxSegOut *seg,
+__global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
                        int frames_per_stream, int NG, int lsf, long long nframes_total);
 __global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes, const int *carry_len);
@@ -76,7 +76,8 @@ struct hx_batch {
     float *d_sb = nullptr, *d_xr = nullptr, *d_etab = nullptr, *d_thr = nullptr;
     // k_msscan / k_prep -> k_alloc: x^(3/4), signs, band start values, stereo decision, pre-echo memory at call start
     float *d_x34 = nullptr, *d_thrprev = nullptr, *d_xrdbg = nullptr;
-    unsigned char *d_sgn = nullptr, *d_msflag = nullptr;
+    unsigned *d_sgn = nullptr;          // the lines' signs, one bit per line: [S][NG][2][HX_SGN_WORDS]
+    unsigned char *d_msflag = nullptr;
     HxBandPrep *d_band = nullptr;
     int *d_msdec = nullptr;
     // k_alloc -> k_pack: quantised lines, segment and frame records, slot lists
@@ -84,7 +85,7 @@ struct hx_batch {
     HxSegOut *d_seg = nullptr, *d_seg2 = nullptr;
     HxFrameOut *d_frm = nullptr, *d_frm2 = nullptr;
     HxSlot *d_slots = nullptr, *d_slots2 = nullptr;
-    unsigned char *d_sgn3 = nullptr;                    // third set of the signs: written by the front end of call n + 2 while call n is packed
+    unsigned *d_sgn3 = nullptr;                    // third set of the signs: written by the front end of call n + 2 while call n is packed
     int *d_lens = nullptr;                              // [2 sets][pre_len | carry_len][S]
     int *frame_stats = nullptr;         // caller's per-frame counters (device), optional
     unsigned char *pk_buf = nullptr; long long pk_stride = 0; int *pk_bytes = nullptr;   // caller's packet buffers (device), optional
@@ -111,7 +112,8 @@ struct hx_batch {
     // that hand granules from the front end to k_alloc makes that safe.
     float *d_xr2 = nullptr, *d_etab2 = nullptr, *d_thr2 = nullptr, *d_x342 = nullptr, *d_thrprev2 = nullptr;
     int *d_msbase2 = nullptr, *d_msdec2 = nullptr;
-    unsigned char *d_bt2 = nullptr, *d_btprev2 = nullptr, *d_sgn2 = nullptr, *d_msflag2 = nullptr;
+    unsigned char *d_bt2 = nullptr, *d_btprev2 = nullptr, *d_msflag2 = nullptr;
+    unsigned *d_sgn2 = nullptr;
     HxBandPrep *d_band2 = nullptr;
     hipStream_t s_front = nullptr, s_alloc = nullptr, s_pack = nullptr;
     hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_alloc[2] = {nullptr, nullptr};     // ev_alloc: a submit's packing is done (everything is)
@@ -252,7 +254,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_etab, sizeof(float) * S * NG * 128);
     ALLOC(b->d_thr, sizeof(float) * S * NG * 128);
     ALLOC(b->d_x34, sizeof(float) * S * NG * 1152);
-    ALLOC(b->d_sgn, S * NG * 1152);
+    ALLOC(b->d_sgn, sizeof(unsigned) * S * NG * 2 * HX_SGN_WORDS);
     ALLOC(b->d_band, sizeof(HxBandPrep) * S * NG);
     ALLOC(b->d_msflag, S * NG);
     ALLOC(b->d_msdec, sizeof(int) * S * NG);
@@ -438,7 +440,7 @@ static int pipe_init(hx_batch *b)
     HIPCHK(hipMalloc((void **) &b->d_seg2, sizeof(HxSegOut) * S * NG * 2));
     HIPCHK(hipMalloc((void **) &b->d_frm2, sizeof(HxFrameOut) * S * NG));
     HIPCHK(hipMalloc((void **) &b->d_slots2, sizeof(HxSlot) * S * (NG + HX_SLOTS_EXTRA)));
-    HIPCHK(hipMalloc((void **) &b->d_sgn3, S * NG * 1152));
+    HIPCHK(hipMalloc((void **) &b->d_sgn3, sizeof(unsigned) * S * NG * 2 * HX_SGN_WORDS));
     HIPCHK(hipMalloc((void **) &b->d_xr2, sizeof(float) * S * NG * 1152));
     HIPCHK(hipMalloc((void **) &b->d_etab2, sizeof(float) * S * NG * 128));
     HIPCHK(hipMalloc((void **) &b->d_thr2, sizeof(float) * S * NG * 128));
@@ -446,7 +448,7 @@ static int pipe_init(hx_batch *b)
     HIPCHK(hipMalloc((void **) &b->d_bt2, S * NG));
     HIPCHK(hipMalloc((void **) &b->d_btprev2, S));
     HIPCHK(hipMalloc((void **) &b->d_x342, sizeof(float) * S * NG * 1152));
-    HIPCHK(hipMalloc((void **) &b->d_sgn2, S * NG * 1152));
+    HIPCHK(hipMalloc((void **) &b->d_sgn2, sizeof(unsigned) * S * NG * 2 * HX_SGN_WORDS));
     HIPCHK(hipMalloc((void **) &b->d_band2, sizeof(HxBandPrep) * S * NG));
     HIPCHK(hipMalloc((void **) &b->d_msflag2, S * NG));
     HIPCHK(hipMalloc((void **) &b->d_msdec2, sizeof(int) * S * NG));
@@ -469,7 +471,7 @@ static int check_call(const hx_batch *b, const void *pcm, int nframes, const voi
 static int enqueue_pack(hx_batch *b, unsigned char *d_out, long long out_stride, int *d_out_bytes, int nframes, int set, int sset, hipStream_t qp)
 {
     const int S = b->S, NG = 2 * nframes;
-    unsigned char *const x_sgn = sset == 2 ? b->d_sgn3 : (sset ? b->d_sgn2 : b->d_sgn);
+    unsigned *const x_sgn = sset == 2 ? b->d_sgn3 : (sset ? b->d_sgn2 : b->d_sgn);
     short *const x_ixq = set ? b->d_ixq2 : b->d_ixq;
     HxSegOut *const x_seg = set ? b->d_seg2 : b->d_seg;
     HxFrameOut *const x_frm = set ? b->d_frm2 : b->d_frm;
@@ -479,7 +481,7 @@ static int enqueue_pack(hx_batch *b, unsigned char *d_out, long long out_stride,
     const long long total = (long long) S * fps;
     LAUNCH(k_pack_pre, dim3(S), dim3(64), qp, (const HxStream *) b->d_st, d_out, out_stride, (const int *) x_prelen);
     LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
-           (const short *) x_ixq, (const unsigned char *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
+           (const short *) x_ixq, (const unsigned *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
            d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total);
     LAUNCH(k_pack_carry, dim3(S), dim3(64), qp, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes, (const int *) x_carrylen);
     return 0;
@@ -556,7 +558,8 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     // (the signs are also read by the packing, which may still be busy with submit n-2 when the front end of submit n
     // writes them: three sets in rotation)
     const int sset = pipelined ? (int) (b->nsubmit % 3) : 0;
-    unsigned char *const x_sgn = sset == 2 ? b->d_sgn3 : (sset ? b->d_sgn2 : b->d_sgn), *const x_msflag = set ? b->d_msflag2 : b->d_msflag;
+    unsigned *const x_sgn = sset == 2 ? b->d_sgn3 : (sset ? b->d_sgn2 : b->d_sgn);
+    unsigned char *const x_msflag = set ? b->d_msflag2 : b->d_msflag;
     short *const x_ixq = set ? b->d_ixq2 : b->d_ixq;
     HxSegOut *const x_seg = set ? b->d_seg2 : b->d_seg;
     HxFrameOut *const x_frm = set ? b->d_frm2 : b->d_frm;
@@ -953,7 +956,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "band") { src = b->d_band; n = sizeof(HxBandPrep) * S * NG; }
     else if (k == "msflag") { src = b->d_msflag; n = S * NG; }
     else if (k == "ixq") { src = b->d_ixq; n = sizeof(short) * S * NG * 1152; }
-    else if (k == "sgn") { src = b->d_sgn; n = S * NG * 1152; }
+    else if (k == "sgn") { src = b->d_sgn; n = (long long) sizeof(unsigned) * S * NG * 2 * HX_SGN_WORDS; }      // one bit per line, HX_SGN_WORDS words per (granule, channel)
     else if (k == "seg") { src = b->d_seg; n = sizeof(HxSegOut) * S * NG * 2; }
     else if (k == "frm") { src = b->d_frm; n = sizeof(HxFrameOut) * S * NG; }
     else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }

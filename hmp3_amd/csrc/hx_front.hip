@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const 
 // (:878-896, pow34.c:132-186), and the masking thresholds after pre-echo control (spdsmr.c:275-318).  The
 // short-block granules are skipped (their allocator starts from the raw spectrum).
 #define PREP_GPB 4      // granules (wavefronts) per workgroup: they share one copy of the lookup tables
-__global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict__ xr, float *__restrict__ xmag_dbg, float *__restrict__ x34o, unsigned char *__restrict__ sgn,
+__global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict__ xr, float *__restrict__ xmag_dbg, float *__restrict__ x34o, unsigned *__restrict__ sgn,
                                              HxBandPrep *__restrict__ band, const HxStream *__restrict__ st,
                                              const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
                                              const unsigned char *__restrict__ bt, const unsigned char *__restrict__ msflag,
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
         // helper wave forms them again from the spectrum it fetches, in time it would otherwise spend waiting - cheaper
         // than 4.8 GB of stores and as many loads per launch.  (xmag_dbg, x34o: the tests' taps.)
         float4 *dq = reinterpret_cast<float4 *>(x34o + unit * 1152);     // (x34o: the tests' tap; the allocator's helper wave computes x^(3/4) again)
-        unsigned *ds = reinterpret_cast<unsigned *>(sgn + unit * 1152);
+        unsigned *ds = sgn + unit * (2 * HX_SGN_WORDS);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int e = lane + 64 * k;
@@ -980,9 +980,18 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
                     dq[e] = make_float4(q0[k][0], q0[k][1], q0[k][2], q0[k][3]);
                     dq[144 + e] = make_float4(q1[k][0], q1[k][1], q1[k][2], q1[k][3]);
                 }
-                ds[e] = s0[k];
-                ds[144 + e] = s1[k];
             }
+            // signs as one bit per line, line order: a lane's four lines are a nibble (its sign bytes' low bits), eight
+            // neighbouring lanes a word - OR over the group of eight on the DPP path, the group's first lane stores it
+            unsigned w0 = ((s0[k] & 1u) | ((s0[k] >> 7) & 2u) | ((s0[k] >> 14) & 4u) | ((s0[k] >> 21) & 8u)) << (4 * (lane & 7));
+            unsigned w1 = ((s1[k] & 1u) | ((s1[k] >> 7) & 2u) | ((s1[k] >> 14) & 4u) | ((s1[k] >> 21) & 8u)) << (4 * (lane & 7));
+            w0 |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) w0, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+            w1 |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) w1, 0xB1, 0xf, 0xf, true);
+            w0 |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) w0, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+            w1 |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) w1, 0x4E, 0xf, 0xf, true);
+            w0 |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) w0, 0x141, 0xf, 0xf, true);     // row_half_mirror: the other quad of the eight
+            w1 |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) w1, 0x141, 0xf, 0xf, true);
+            if ((lane & 7) == 0 && e < 144) { ds[e >> 3] = w0; ds[HX_SGN_WORDS + (e >> 3)] = w1; }
         }
     }
 #undef WAVE_SYNC

@@ -14,7 +14,7 @@
 struct alignas(16) PackLds {
     unsigned bitw[640];                 // the frame's main data, MSB-first 32-bit words
     unsigned short ix[4][576];          // per segment: quantised magnitudes ...
-    unsigned char sg[4][576];           // ... and signs
+    unsigned sg[4][HX_SGN_WORDS];       // ... and signs, one bit per line
     unsigned short huff_code[1408];
     unsigned char huff_len[1408];
     int tabpk[32];                      // per Huffman table: code offset | row stride << 12 | linbits << 20
@@ -43,7 +43,7 @@ __device__ __forceinline__ void put_bits64(PackLds &L, int pos, unsigned long lo
 // Huffman-code one segment; returns the new bit position.  Phase A builds the code word of every pair (five per
 // lane, table parameters of the three regions read once and picked with selects: independent chains, no
 // branches); phase B places them with a wave prefix sum of the lengths per 64 pairs.  Then the count1 quads.
-__device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsigned r2q, unsigned tabs, const unsigned short *ix, const unsigned char *sgn, int lane)
+__device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsigned r2q, unsigned tabs, const unsigned short *ix, const unsigned *sgn, int lane)
 {
     const int n0 = r01 & 0xFFFF, n1 = r01 >> 16, n2 = r2q & 0xFFFF;
     const int npairs = n0 + n1 + n2;
@@ -56,7 +56,7 @@ __device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsi
         for (int k = 0; k < 5; k++) {
             const int pc = min(lane + 64 * k, 287);
             xy[k] = reinterpret_cast<const unsigned *>(ix)[pc];
-            sn[k] = reinterpret_cast<const unsigned short *>(sgn)[pc];
+            sn[k] = (sgn[pc >> 4] >> (2 * (pc & 15))) & 3u;         // the pair's two sign bits
         }
         int o[5];
 #pragma unroll
@@ -81,7 +81,7 @@ __device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsi
             if (x) { v = (v << 1) | (sn[k] & 1u); l++; }
             v = (v << ly) | (unsigned) ((y >= 15) ? y - 15 : 0);
             l += ly;
-            if (y) { v = (v << 1) | ((sn[k] >> 8) & 1u); l++; }
+            if (y) { v = (v << 1) | ((sn[k] >> 1) & 1u); l++; }
             val[k] = v;
             len[k] = (pi < npairs && dim != 0) ? l : 0;
         }
@@ -103,17 +103,17 @@ __device__ __forceinline__ int pack_huff(PackLds &L, int pos, unsigned r01, unsi
         const int q = lane + 64 * k, qc = min(q, max(nq - 1, 0));
         const unsigned *v2 = reinterpret_cast<const unsigned *>(ix + qb + 4 * qc);
         const unsigned a = v2[0], b = v2[1];
-        const unsigned short *s2 = reinterpret_cast<const unsigned short *>(sgn + qb + 4 * qc);
-        const unsigned s4 = (unsigned) s2[0] | ((unsigned) s2[1] << 16);
+        const int sp = qb + 4 * qc;                 // (even: the quad's four bits lie in one word or straddle two)
+        const unsigned s4 = (unsigned) ((((unsigned long long) sgn[min((sp >> 5) + 1, HX_SGN_WORDS - 1)] << 32) | sgn[sp >> 5]) >> (sp & 31)) & 15u;
         const int code = (int) (((a & 0xFFFF) << 3) + ((a >> 16) << 2) + ((b & 0xFFFF) << 1) + (b >> 16));
         unsigned v;
         int l;
         if (c1sel == 1) { v = code ^ 15; l = 4; }
         else { v = L.quada_code[code & 15]; l = L.quada_len[code & 15]; }
         if (code & 8) { v = (v << 1) | (s4 & 1u); l++; }
-        if (code & 4) { v = (v << 1) | ((s4 >> 8) & 1u); l++; }
-        if (code & 2) { v = (v << 1) | ((s4 >> 16) & 1u); l++; }
-        if (code & 1) { v = (v << 1) | ((s4 >> 24) & 1u); l++; }
+        if (code & 4) { v = (v << 1) | ((s4 >> 1) & 1u); l++; }
+        if (code & 2) { v = (v << 1) | ((s4 >> 2) & 1u); l++; }
+        if (code & 1) { v = (v << 1) | ((s4 >> 3) & 1u); l++; }
         qval[k] = v;
         qlen[k] = (q < nq) ? l : 0;
     }
@@ -185,7 +185,7 @@ __device__ __noinline__ void unmasked_writer_fixup(PackLds &L, int nseg)
 // code tables once and then takes every gridDim.x-th frame.
 __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, const HxParams *__restrict__ prm,
                                               const HxGlobalTabs *__restrict__ gt, const short *__restrict__ ixq,
-                                              const unsigned char *__restrict__ sgn, const HxSegOut *__restrict__ seg,
+                                              const unsigned *__restrict__ sgn, const HxSegOut *__restrict__ seg,
                                               const HxFrameOut *__restrict__ frm, const HxSlot *__restrict__ slots,
                                               unsigned char *__restrict__ out, long long out_stride, unsigned char *__restrict__ packet,
                                               int *__restrict__ status, int frames_per_stream, int NG, int lsf, long long nframes_total)
@@ -221,12 +221,12 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
             h1 = reinterpret_cast<const int2 *>(so)[2];
             if (lane < 40) fld = so->sf[lane];
             const uint4 *sx = reinterpret_cast<const uint4 *>(ixq + unit * 576);
-            const uint4 *ss = reinterpret_cast<const uint4 *>(sgn + unit * 576);
+            const uint4 *ss = reinterpret_cast<const uint4 *>(sgn + unit * HX_SGN_WORDS);
             uint4 *dx = reinterpret_cast<uint4 *>(&L.ix[w][0]), *ds = reinterpret_cast<uint4 *>(&L.sg[w][0]);
-            const uint4 a0 = sx[lane], a1 = sx[64 + (lane & 7)], a2 = ss[min(lane, 35)];
+            const uint4 a0 = sx[lane], a1 = sx[64 + (lane & 7)], a2 = ss[min(lane, HX_SGN_WORDS / 4 - 1)];
             dx[lane] = a0;
             if (lane < 8) dx[64 + lane] = a1;
-            if (lane < 36) ds[lane] = a2;
+            if (lane < HX_SGN_WORDS / 4) ds[lane] = a2;
         }
         const int not_null = h1.y;
         if (lane < 40) L.sf[w][lane] = (unsigned short) fld;

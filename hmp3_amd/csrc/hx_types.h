@@ -184,6 +184,11 @@ struct alignas(16) HxFrameOut {
 #define K1_GPB 14
 #define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
 
+// The lines' signs travel from k_prep (or, for short-block and first-generation-allocator granules, the stream walk) to
+// k_pack as one bit per line: 576 bits = 18 words per (granule, channel), padded to 20 so that a granule's 160 bytes keep
+// 16-byte alignment.  (As one byte per line they were 0.6 GB written and 0.6 GB read per config-2 step.)
+#define HX_SGN_WORDS 20
+
 // Arguments of the allocator kernels (k_alloc / k_alloc_lsf), filled by the host runtime.
 struct AllocArgs {
     HxStream *st;
@@ -211,14 +216,14 @@ struct AllocArgs {
     int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter)
     // from k_msscan / k_prep (hx_front.hip); xr holds the coded magnitudes for long-block granules
     const float *x34;           // [S][NG][2][576] x^(3/4) of the magnitudes (long-block granules)
-    const unsigned char *sgn;   // [S][NG][2][576] sign of each line
+    const unsigned *sgn;        // [S][NG][2][HX_SGN_WORDS] sign of each line, one bit per line in line order (bit j & 31 of word j >> 5)
     const HxBandPrep *band;     // [S][NG]
     const unsigned char *msflag;    // [S][NG] 1 = the granule's frame is coded M/S
     const int *msdec;           // [S][NG] the stereo metric after hysteresis (debug taps)
     const float *thrprev;       // [S][2][64] pre-echo memory the call started with
     // to k_pack (hx_pack.hip)
     short *ixq;                 // [S][NG][2][576] quantised magnitudes
-    unsigned char *sgn_w;       // the sign buffer again, writable: short-block granules store their reordered signs
+    unsigned *sgn_w;            // the sign buffer again, writable: short-block granules store their reordered signs
     HxSegOut *seg;              // [S][NG][2]
     HxFrameOut *frm;            // [S][frames per call]
     HxSlot *slots;              // [S][frames per call + HX_SLOTS_EXTRA]

@@ -650,7 +650,9 @@ def test_every_stage_bit_exact(name):
     thr = b.debug_read("thr", np.float32, S * NG * 128).reshape(S, NG, 2, 64)
     btg = b.debug_read("bt", np.uint8, S * NG).reshape(S, NG)
     ixq = b.debug_read("ixq", np.int16, S * NG * 1152).reshape(S, NG, 2, 576).astype(np.int32) & 0xFFFF
-    sgn = b.debug_read("sgn", np.uint8, S * NG * 1152).reshape(S, NG, 2, 576)
+    # the signs travel as one bit per line (bit j & 31 of word j >> 5; 20 words per granule and channel, 18 used)
+    sgw = b.debug_read("sgn", np.uint32, S * NG * 2 * 20).reshape(S, NG, 2, 20)
+    sgn = np.unpackbits(sgw[..., :18].copy().view(np.uint8), axis=-1, bitorder="little").reshape(S, NG, 2, 576)
     npart = np.zeros(1, np.int32)
     assert api().lib().hx_debug_host_table(C.byref(api().default_control(**kw)), b"psy_npart", npart.ctypes.data, 4) == 4
     np2 = int(npart[0] + 1) & ~1
