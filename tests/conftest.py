@@ -32,9 +32,15 @@ def has_gpu():
 # Every GPU test runs twice: on k_alloc (the stream walk written for four streams per CU) and on k_alloc_slim (its
 # low-footprint build, six per CU), forced through the library's environment switch; the bytes must not differ.
 # (MPEG-2 and first-generation-allocator batches have one kernel each and ignore the switch.)
+# tests whose batches never reach the switch (MPEG-2 rates and first-generation-allocator streams have one kernel each; the
+# whole-file sweep against the reference's binary and the two-device tests are long and about something else): once
+ONE_BUILD = ("mpeg2", "lsf", "intensity", "negative_scalefactors", "fuzz_cli", "two_physical", "extra_golden", "src_convert")
+
+
 def pytest_generate_tests(metafunc):
     if metafunc.definition.get_closest_marker("gpu") is not None and "k6_build" in metafunc.fixturenames:
-        metafunc.parametrize("k6_build", ["fat", "slim"], indirect=True)
+        once = any(p in metafunc.function.__name__ for p in ONE_BUILD)
+        metafunc.parametrize("k6_build", ["fat"] if once else ["fat", "slim"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
