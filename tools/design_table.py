@@ -1,0 +1,62 @@
+"""DESIGN.md section 4's table of current numbers, generated from profiles/ and the kernels' own resource notes:
+   python tools/design_table.py r04 [--listings DIR]
+Per kernel and BASELINE config (2 = 1024 x 256, 3 = 4096 x 256): mean duration in the bench run (rocprofv3 --kernel-trace
+--stats; under the overlap, so a front-end kernel's duration includes its wait for the allocator's LDS), HBM bytes per launch
+(2 x FETCH_SIZE + WRITE_SIZE), vector-issue share (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), waiting share (SQ_WAIT_ANY /
+SQ_WAVE_CYCLES), LDS bank-conflict share (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); VGPRs, LDS bytes and scratch bytes from the
+code objects' metadata (listings compiled with the product's flags by tools/check_lds_flat.py --keep)."""
+import csv
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+lst = sys.argv[sys.argv.index("--listings") + 1] if "--listings" in sys.argv else None
+if lst is None:
+    lst = tempfile.mkdtemp(prefix="hxlst.")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "check_lds_flat.py"), "--keep", lst], stdout=subprocess.DEVNULL)
+res = {}
+for f in os.listdir(lst):
+    if not f.endswith(".s"):
+        continue
+    txt = open(os.path.join(lst, f)).read()
+    for m in re.finditer(r"\.group_segment_fixed_size: (\d+).*?\.name:\s+(\w+).*?\.private_segment_fixed_size: (\d+).*?\.vgpr_count:\s+(\d+)", txt, re.S):
+        name = subprocess.run(["c++filt", m.group(2)], capture_output=True, text=True).stdout.split("(")[0].strip()
+        res[name] = dict(lds=int(m.group(1)), scratch=int(m.group(3)), vgpr=int(m.group(4)))
+
+
+def stats(cfg):
+    p = os.path.join(ROOT, "profiles", "%s_kernel_stats_bench_config%d.csv" % (R, cfg))
+    return {r["Name"].split("(")[0]: float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(p))} if os.path.exists(p) else {}
+
+
+def pmc(cfg, shape):
+    p = os.path.join(ROOT, "profiles", "%s_pmc_counters_config%d_%s.json" % (R, cfg, shape))
+    return json.load(open(p))["kernels"] if os.path.exists(p) else {}
+
+
+s2, s3, p2, p3 = stats(2), stats(3), pmc(2, "1024x256"), pmc(3, "4096x256")
+order = ["k_polyphase", "k_spec", "k_prep", "k_alloc", "k_alloc_slim", "k_pack", "k_msscan", "k_blocktype", "k_attack_flg", "k_attack_eng", "k_carry", "k_pack_carry", "k_pack_pre", "k_order"]
+print("| kernel | VGPRs | LDS B | scratch B | ms cfg 2 | ms cfg 3 | GB cfg 2 | GB cfg 3 | vector issue | waiting | LDS conflicts |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
+tot2 = tot3 = 0.0
+for k in order:
+    r = res.get(k, {})
+    c = p2.get(k) or p3.get(k) or {}
+    g2 = p2.get(k, {}).get("hbm_bytes_corrected")
+    g3 = p3.get(k, {}).get("hbm_bytes_corrected")
+    tot2 += g2 or 0
+    tot3 += g3 or 0
+
+    def pct(a, b):
+        return "%.0f %%" % (100.0 * c[a] / c[b]) if c.get(b) else "-"
+    print("| `%s` | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+        k, r.get("vgpr", "-"), r.get("lds", "-"), r.get("scratch", "-"),
+        "%.3f" % s2[k] if k in s2 else "-", "%.3f" % s3[k] if k in s3 else "-",
+        "%.2f" % (g2 / 1e9) if g2 else "-", "%.2f" % (g3 / 1e9) if g3 else "-",
+        pct("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"), pct("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), pct("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")))
+print("| **step total** | | | | | | **%.2f** | **%.2f** | | | |" % (tot2 / 1e9, tot3 / 1e9))
