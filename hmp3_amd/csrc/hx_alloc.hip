@@ -249,6 +249,16 @@ __device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int 
 // Rarely taken paths are kept out of line, away from the hot code: the kernel's instructions do not fit
 // the instruction cache that the waves of a CU share (DESIGN.md, K6 in detail).
 #define HX_COLD __attribute__((noinline, cold))
+// The rate loop's correction paths (increase_bits, decrease_bits, limit_bits and the requantise-and-count they share) run in a
+// minority of granules, but a launch ends with its slowest stream and that stream is one that lives in them: out of line like
+// the cold functions (their code stays away from the common path's), but compiled for speed, not - as `cold` implies - for size.
+// (Measured: config 2 +2.2 %, its worst-case signal set +2.4 %.  The 168-register build keeps them cold: compiled for speed they
+// pull their callees in, the kernel grows by 6 KB and its scalar spills by 55: config 3 -2.2 %.)
+#if HX_SLIM
+#define HX_RATE HX_COLD
+#else
+#define HX_RATE __attribute__((noinline))
+#endif
 // The lane number as a value the compiler cannot see through, taken once per function (HX_LANE_DECL at its top; LANE is that
 // local).  As the pure threadIdx.x & 63 every predicate and LDS address derived from it - i < NB, LANE < 44, base + 4 * lane,
 // dozens of them after inlining - is loop-invariant, gets hoisted out of the frame loop and stays live over all of it: some
