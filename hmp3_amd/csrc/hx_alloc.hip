@@ -249,6 +249,8 @@ __device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int 
 // Rarely taken paths are kept out of line, away from the hot code: the kernel's instructions do not fit
 // the instruction cache that the waves of a CU share (DESIGN.md, K6 in detail).
 #define HX_COLD __attribute__((noinline, cold))
+// The -HF helpers: out of line (most configurations never call them), but with -HF on they run in every granule: for speed.
+#define HX_HFN __attribute__((noinline))
 // The rate loop's correction paths (increase_bits, decrease_bits, limit_bits and the requantise-and-count they share) run in a
 // minority of granules, but a launch ends with its slowest stream and that stream is one that lives in them: out of line like
 // the cold functions (their code stays away from the common path's), but compiled for speed, not - as `cold` implies - for size.
