@@ -256,10 +256,13 @@ __device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int 
 // the cold functions (their code stays away from the common path's), but compiled for speed, not - as `cold` implies - for size.
 // (Measured: config 2 +2.2 %, its worst-case signal set +2.4 %.  The 168-register build keeps them cold: compiled for speed they
 // pull their callees in, the kernel grows by 6 KB and its scalar spills by 55: config 3 -2.2 %.)
-#if HX_SLIM
-#define HX_RATE HX_COLD
-#else
+#ifndef HX_RATE_SPEED
+#define HX_RATE_SPEED (!HX_SLIM)
+#endif
+#if HX_RATE_SPEED
 #define HX_RATE __attribute__((noinline))
+#else
+#define HX_RATE HX_COLD
 #endif
 // The lane number as a value the compiler cannot see through, taken once per function (HX_LANE_DECL at its top; LANE is that
 // local).  As the pure threadIdx.x & 63 every predicate and LDS address derived from it - i < NB, LANE < 44, base + 4 * lane,
