@@ -569,7 +569,9 @@ def main():
                 gi = kc["SQ_INSTS_VALU"] / (k_ms * 1e-3) / 1e9
                 valu = {"bound": "valu_issue", "kernel": kernel, "achieved": round(gi, 2), "peak": VALU_PEAK_GINST, "unit": "Ginst/s (wave64 vector instructions)",
                         "frac": round(gi / VALU_PEAK_GINST, 4), "insts_per_launch": int(kc["SQ_INSTS_VALU"]),
-                        "waves_per_simd": round(kc.get("SQ_WAVES", 0) / 1024.0, 2),
+                        # waves of this kernel resident per SIMD while the launch is full: 2 per stream (master + helper)
+                        "waves_per_simd": round(2.0 * min(S, m["k6"]["resident_streams"]) / (4.0 * torch.cuda.get_device_properties(local).multi_processor_count), 2) if m.get("k6") else None,
+                        "waves_launched": int(kc.get("SQ_WAVES", 0)),
                         "lds_bank_conflict_frac": round(kc["SQ_LDS_BANK_CONFLICT"] / kc["SQ_LDS_IDX_ACTIVE"], 4) if kc.get("SQ_LDS_IDX_ACTIVE") else None,
                         "valu_active_over_wave_cycles": round(kc["SQ_ACTIVE_INST_VALU"] / kc["SQ_WAVE_CYCLES"], 4) if kc.get("SQ_WAVE_CYCLES") else None,
                         "counters": prof[1]}
