@@ -416,3 +416,27 @@ def test_soak_slice_six_thousand_frames_in_calls_of_1_to_64():
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     assert out.count(" ok") == 2 and "6000 frames x 2 streams" in out
+
+
+def test_host_placement_helpers_are_best_effort_and_harmless(k6_build):
+    """hx_device_numa_node / hx_bind_thread_to_device: the node of device 0 (or -1), and binding the calling thread to its
+    CPUs never enlarges the thread's CPU set and leaves it usable (bench.py does this in every rank before it allocates
+    page-locked buffers); an encode afterwards still matches the oracle"""
+    a = api()
+    before = os.sched_getaffinity(0)
+    try:
+        node = a.device_numa_node(0)
+        n = a.bind_thread_to_device(0)
+        after = os.sched_getaffinity(0)
+        assert node >= -1 and n >= 0
+        assert after <= before and len(after) >= 1
+        assert n in (0, len(after))
+        assert a.device_numa_node(99) == -1 and a.bind_thread_to_device(99) == 0      # no such device: nothing happens
+        kw = dict(bitrate=64)
+        pcm = np.stack([synth.stream_pcm(70 + i, 6, rho=RHOS[i % 4]) for i in range(4)])
+        b = a.Batch(a.default_control(**kw), nstreams=4, max_frames=6)
+        got = b.encode_host(pcm)
+        assert b.status() == 0 and all(got[s] == oracle_bytes(kw, pcm[s], 6) for s in range(4))
+        b.close()
+    finally:
+        os.sched_setaffinity(0, before)

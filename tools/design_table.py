@@ -60,3 +60,27 @@ for k in order:
         "%.2f" % (g2 / 1e9) if g2 else "-", "%.2f" % (g3 / 1e9) if g3 else "-",
         pct("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"), pct("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), pct("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")))
 print("| **step total** | | | | | | **%.2f** | **%.2f** | | | |" % (tot2 / 1e9, tot3 / 1e9))
+
+
+# ---- section 5: the bench lines of the four BASELINE configurations ----
+print()
+print("| BASELINE config (one GPU's share) | frames/s | × real-time | ms / step | K6 kernel, ms | step − K6 | roofline (HBM) | verified |")
+print("|---|---|---|---|---|---|---|---|")
+for cfg in (2, 3, 4, 5):
+    p = os.path.join(ROOT, "profiles", "%s_bench_line_config%d.json" % (R, cfg))
+    if not os.path.exists(p):
+        continue
+    d = json.load(open(p))
+    r = d["roofline"]
+    print("| %d: %s | **%.2f M** | %.0f k | %.2f | %s %.2f | %.2f | %.2f %% | %s / %s |" % (
+        cfg, d["config"]["workload"].split(" per step")[0], d["value"] / 1e6, d["x_realtime_per_gpu"] / 1e3, d["ms_per_step"], r["kernel"], r["kernel_ms"],
+        d["ms_per_step"] - r["kernel_ms"], 100.0 * r["frac"], d.get("verified_streams"), d.get("verify", {}).get("checked")))
+    if cfg == 2:
+        w, h, c = d.get("worst_case", {}), d.get("host_fed", {}), d.get("cpu_baseline", {})
+        extra = ["| 2, correlation cycled over {0.7, 0, 1, 0.3} (`worst_case_value`) | %.2f M | | %.2f | %.2f | | | |" % (d.get("worst_case_value", 0) / 1e6, w.get("ms_per_step", 0), w.get("kernel_ms", 0)),
+                 "| 2, fed from page-locked host memory (`host_fed`, PCIe both ways in the timed region) | %.2f M | | %.2f | | | H2D %.1f GB/s | |" % (h.get("value", 0) / 1e6, h.get("ms_per_step", 0), h.get("h2d_GBps", 0)),
+                 "| the reference itself on the box's usable host CPUs (`cpu_baseline`, kind %s, %s cores) | %.3f M | | | | | | |" % (c.get("kind"), c.get("cores"), (c.get("value") or 0) / 1e6)]
+        print("\n".join(extra))
+        for o in d.get("other_configs", []):
+            print("| %d, inside the config-2 line (`other_configs`, 4 timed steps) | %.2f M | | %.2f | %s %.2f | %.2f | %.2f %% | %s / %s |" % (
+                o["baseline_config"], o["value"] / 1e6, o["ms_per_step"], o["kernel_build"], o["kernel_ms"], o["ms_per_step"] - o["kernel_ms"], 100.0 * (o["roofline_frac"] or 0), o["verified_streams"], o["verify_checked"]))
