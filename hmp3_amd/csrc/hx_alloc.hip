@@ -481,11 +481,15 @@ __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl
             qx[k3] = (int) (tmp + copysignf(0.5f, tmp));
             t[k3] = noise_term_fast(L, ig, gn[k3], x34, xr[k3]);
         }
+        // (a chunk none of whose 192 lines quantises beyond the float table - the loud lines sit in a few low bands - does not
+        // go to the double table at all: its memory round trip is most of this pass)
+        if (__any(qx[0] >= 256 || qx[1] >= 256 || qx[2] >= 256)) {
 #pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) pw[k3] = L.pow43[min(max(qx[k3], 0), HX_POW43_N - 1)];
+            for (int k3 = 0; k3 < 3; k3++) pw[k3] = L.pow43[min(max(qx[k3], 0), HX_POW43_N - 1)];
 #pragma unroll
-        for (int k3 = 0; k3 < 3; k3++)
-            if (qx[k3] >= 256) { const float d = xr[k3] - noise_xhat_big(L, qx[k3], pw[k3], gn[k3]); t[k3] = d * d; }
+            for (int k3 = 0; k3 < 3; k3++)
+                if (qx[k3] >= 256) { const float d = xr[k3] - noise_xhat_big(L, qx[k3], pw[k3], gn[k3]); t[k3] = d * d; }
+        }
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
     }
@@ -906,13 +910,18 @@ __device__ __noinline__ void lucky_terms_big(AllocLds &L, int nl, int ncmax, flo
             qx[q] = (int) (tmp + copysignf(0.5f, tmp));
             v[q] = noise_term_fast(L, ig, gn[q], sx34[q], sxr[q]);
         }
+        bool anybig = false;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) pw[q] = L.pow43[min(max(qx[q], 0), HX_POW43_N - 1)];
+        for (int q = 0; q < NQ; q++) anybig = anybig || qx[q] >= 256;
+        if (__any(anybig)) {        // (a candidate none of whose lines passes the float table skips the double table's round trip)
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            if (qx[q] >= 256) { const float d = sxr[q] - noise_xhat_big(L, qx[q], pw[q], gn[q]); v[q] = d * d; }
-            base[q][c * stride[q]] = v[q];
+            for (int q = 0; q < NQ; q++) pw[q] = L.pow43[min(max(qx[q], 0), HX_POW43_N - 1)];
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (qx[q] >= 256) { const float d = sxr[q] - noise_xhat_big(L, qx[q], pw[q], gn[q]); v[q] = d * d; }
         }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) base[q][c * stride[q]] = v[q];
     }
 }
 
