@@ -1273,7 +1273,9 @@ static int read_int_file(const char *path, int *v)
 extern "C" int hx_device_numa_node(int device)
 {
     char bus[64] = {0}, path[256];
-    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void) hipGetLastError(); return -1; }
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) { (void) hipGetLastError(); return -1; }     // (the error is not left behind for the next launch check)
     for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char) (*c - 'A' + 'a');      // sysfs spells the address in lower case
     snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
     int node = -1;

@@ -931,14 +931,19 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
         for (int c = 0; c < 4; c++) {
             const int j = 4 * e + c, bnd = (bl >> (8 * c)) & 255;
             q0[k][c] = q1[k][c] = 0.0f;
-            if (e < 144 && j < nl_p0) { q0[k][c] = hx_pow34(t_a, t_b, t_exp, a0[k][c]); atomicMax(&xmax[wv][0][bnd], __float_as_int(q0[k][c])); }
-            if (e < 144 && j < nl_p1) { q1[k][c] = hx_pow34(t_a, t_b, t_exp, a1[k][c]); atomicMax(&xmax[wv][1][bnd], __float_as_int(q1[k][c])); }
+            // The band maximum of x^(3/4) is the x^(3/4) of the band's largest magnitude: the piecewise-linear fit is monotone
+            // over every non-negative float (checked exhaustively: tools/check_pow34_monotone.cpp).  So the lines contribute
+            // their magnitudes (sign bit off: lines past the magnitude range are raw, and the fit ignores the sign), and the
+            // band lane evaluates the fit once - 44 evaluations per granule instead of 1152.  The lines' own x^(3/4) is only
+            // formed for the tests' tap (the allocator's helper wave computes it for itself).
+            if (e < 144 && j < nl_p0) { atomicMax(&xmax[wv][0][bnd], __float_as_int(a0[k][c]) & 0x7FFFFFFF); if (x34o) q0[k][c] = hx_pow34(t_a, t_b, t_exp, a0[k][c]); }
+            if (e < 144 && j < nl_p1) { atomicMax(&xmax[wv][1][bnd], __float_as_int(a1[k][c]) & 0x7FFFFFFF); if (x34o) q1[k][c] = hx_pow34(t_a, t_b, t_exp, a1[k][c]); }
         }
     }
     WAVE_SYNC();
     int gz = 0;
     float xm = 0.0f;
-    if (i < 22) xm = __int_as_float(xmax[wv][ch][i]);
+    if (i < 22) xm = hx_pow34(t_a, t_b, t_exp, __int_as_float(xmax[wv][ch][i]));
     if (i < (ch ? nb_z1 : nb_z0)) gz = max(0, hx_round((0.017716950f * hx_mblog(t_mblog, xm) + (104.585000f - 100.0f + 8.0f))));
     // masking threshold of the band: the two partitions' thresholds, each clamped against twice the previous
     // granule's unless this is a stop block, weighted by the partitions' energies
