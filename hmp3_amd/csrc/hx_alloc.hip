@@ -1,8 +1,12 @@
 // hx_alloc.hip - K6: per-stream rate loop of the batched MP3 encoder for MI355X (gfx950).
-// One wavefront (64 lanes) owns one stream and walks its frames in order, because the
+// One workgroup of two wavefronts (a master that runs the encoder, a helper that takes channel 1's share
+// and the traffic with HBM) owns one stream and walks its frames in order, because the
 // allocator state (long-term MNR, per-band gain estimators, bit reservoir, scfsi memory)
 // is carried frame to frame (reference bitallo3.cpp:484-3149, mp3enc.cpp:1492-1597,
 // :2106-2333, l3pack.c:107-1187, bitalloc.cpp:470-811).
+// This source is compiled five times: k_alloc and k_alloc_slim (MPEG-1; 256 registers and 38 KB of LDS per
+// stream, four streams per CU - or 168 registers and 26 KB, six per CU: HX_SLIM, hx_alloc_slim.hip),
+// k_alloc_lsf (MPEG-2 rates), k_alloc1 / k_alloc1_lsf (the reference's first-generation allocator).
 //
 // Inside a granule the work is spread over the lanes three ways:
 //   line-parallel   quantise / x^(3/4) / M-S butterflies / noise terms / Huffman lengths
