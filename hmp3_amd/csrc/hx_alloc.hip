@@ -122,6 +122,7 @@ struct alignas(16) AllocLds {
     alignas(16) HxBandPrep band_next;               // the next granule's band start values, landed by LDS-DMA while this granule's are still in use
 #else
     unsigned long long sgnbits[2][9];               // short blocks: sign of line t of channel c = bit t & 63 of word t >> 6
+    ix_t ixsink;                                    // where the quantiser's store of a line it must leave alone goes
 #endif
     unsigned char band_of_line[576];
     // tables staged from global memory
@@ -1042,6 +1043,9 @@ __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int 
     // all nine lines of a lane in one basic block: band -> igain -> rounding offset are dependent LDS reads, the nine
     // chains overlap; stores (and the band maxima) come after all loads
     const int nl = p->nbmax[c];
+#if HX_SLIM
+    const int nfill = (opt & 2) ? nl : 576;
+#endif
     int q[9], b[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) b[k] = L.band_of_line[LANE + 64 * k];
@@ -1049,7 +1053,7 @@ __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int 
     for (int k = 0; k < 9; k++) {
         const int j = LANE + 64 * k;
         const float igain = L.gig[c][b[k]];
-        if (opt) {
+        if (opt & 1) {
             float t = igain * L.x34[c][j] + (0.5f - 0.4375f);
             int iq = (int) t;
             if (iq > 31) iq = 31;
@@ -1062,10 +1066,12 @@ __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int 
     for (int k = 0; k < 9; k++) {
         const int j = LANE + 64 * k;
 #if HX_SLIM
-        // the line buffer held noise terms before: every line is written, zeros past the coded range
+        // the line buffer held noise terms before: every line is written, zeros past the coded range - unless the buffer
+        // holds this granule's lines already (opt & 2: the L/R rate loop's step towards more bits): there the reference
+        // leaves what an earlier -HF pass put into band 21, and its count of the last quadruples can reach into it
         // (one value, one unconditional store: written as two conditions the compiler made two exec-masked paths per line)
         const int qq = (j < nl) ? q[k] : 0;
-        IX(c)[j] = (ix_t) qq;
+        *((j < nfill) ? &IX(c)[j] : &L.ixsink) = (ix_t) qq;
         if (qq > 0) atomicMax(&L.ixmax[c][b[k]], qq);
 #else
         if (j < nl) {

@@ -23,6 +23,8 @@ __global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int 
 __global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
 __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                        float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
+__global__ void k_spec_direct(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
+                              float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
 __global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf, int nchan);
 __global__ void k_msscan(HxStream *st, const HxParams *prm, const int *msbase, const unsigned char *bt, unsigned char *msflag, int *msdec,
                          const float *thr, float *thrprev, int NG, int lsf);
@@ -583,8 +585,11 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
            b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
     LAUNCH(k_blocktype, dim3((S + 63) / 64), dim3(64), q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
-    LAUNCH(k_spec, dim3((unsigned) ((long long) S * nframes)), dim3(128), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
-           x_etab, x_thr, x_msbase, NG, SG);
+    // (the form of K4 that goes with the stream-walk kernel: hx_front.hip, spec_granule)
+    if (b->slim) LAUNCH(k_spec_direct, dim3((unsigned) ((long long) S * nframes)), dim3(128), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
+                        x_etab, x_thr, x_msbase, NG, SG);
+    else LAUNCH(k_spec, dim3((unsigned) ((long long) S * nframes)), dim3(128), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
+                x_etab, x_thr, x_msbase, NG, SG);
     // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
     // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
     LAUNCH(k_msscan, dim3(S), dim3(64), q, b->d_st, b->d_prm, x_msbase, x_bt, x_msflag, x_msdec, x_thr, x_thrprev, NG, b->lsf);

@@ -605,16 +605,23 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
     if (lane == 0) *out = v;
 }
 
-__global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, const HxStream *__restrict__ st,
+// DIRECT = false: the granule's subband samples are staged in LDS by 16-byte loads and picked up from there (24 KB of LDS per
+// workgroup); DIRECT = true: every lane loads its own 2 x 18 samples from global memory (8-byte loads; 14.8 KB).  Measured
+// (EXPERIMENTS.md, round 4): alone on the chip the direct form is 11 % faster (configs 3 - 5, where the stream walk's
+// low-footprint kernel leaves the front end no room beside it: +3.6 / +2.7 % per step); beside the resident stream walk of
+// config 2 it is 0.7 % slower per step - more of its smaller workgroups fit next to the walk's waves and take issue slots
+// from them.  hx_cabi.hip launches the form that goes with the stream-walk kernel it chose.
+template <bool DIRECT>
+__device__ __forceinline__ void spec_granule(const float *__restrict__ sb, const HxStream *__restrict__ st,
                                              const HxParams *__restrict__ prm, const HxGlobalTabs *__restrict__ gt,
                                              const unsigned char *__restrict__ bt,
                                              float *__restrict__ xr, float *__restrict__ etab_out, float *__restrict__ thr_out,
                                              int *__restrict__ msbase, int NG, int SG)
 {
     // in: [ch][S[g-3] | S[g-2]][576] subband samples; the first 2 x 576 floats are reused as the
-    // spectrum [ch][576] once every lane holds its inputs in registers
+    // spectrum [ch][576] once every lane holds its inputs in registers (DIRECT: the spectrum only)
     // two granules per workgroup, one wavefront each, independent of each other but for the lookup tables they share
-    __shared__ __attribute__((aligned(16))) float in_s[2][2][2][576];
+    __shared__ __attribute__((aligned(16))) float in_s[2][DIRECT ? 1 : 2][2][576];
     __shared__ float xtab_s[2][2][64];
     __shared__ float es_s[2][3][64];
     __shared__ SpecTabs T;
@@ -639,19 +646,31 @@ __global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, cons
     __syncthreads();        // the tables (the only workgroup barrier: from here on each wave is on its own)
     const int nsb = p->nsb_ms0;
     const int btype = bt[sg];
-    {   // 2 x 1152 contiguous floats per channel, 16 bytes per lane and load
-        float4 v[9];
+    float g1[DIRECT ? 18 : 1], g2[DIRECT ? 18 : 1];
+    const float *x1, *x2;
+    if constexpr (DIRECT) {
+        // every lane takes its subband's 18 + 18 samples straight from global memory (72 contiguous bytes per block, 8-byte
+        // aligned; the wave's 64 lanes cover two contiguous 2304-byte runs per channel)
+        const float2 *b1 = reinterpret_cast<const float2 *>(sb + ((long long) (s * 2 + ch) * SG + g) * 576 + sbnd * 18);
+        const float2 *b2 = b1 + 288;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int e = lane + 64 * k, c = e / 288, r = e - 288 * c;       // 288 float4 per channel
-            v[k] = reinterpret_cast<const float4 *>(sb + ((long long) (s * 2 + c) * SG + g) * 576)[r];
+        for (int i = 0; i < 9; i++) { const float2 a = b1[i], b = b2[i]; g1[2 * i] = a.x; g1[2 * i + 1] = a.y; g2[2 * i] = b.x; g2[2 * i + 1] = b.y; }
+        x1 = g1; x2 = g2;
+    } else {
+        {   // 2 x 1152 contiguous floats per channel, 16 bytes per lane and load
+            float4 v[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int e = lane + 64 * k, c = e / 288, r = e - 288 * c;       // 288 float4 per channel
+                v[k] = reinterpret_cast<const float4 *>(sb + ((long long) (s * 2 + c) * SG + g) * 576)[r];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) reinterpret_cast<float4 *>(&in[0][0][0])[lane + 64 * k] = v[k];
         }
-#pragma unroll
-        for (int k = 0; k < 9; k++) reinterpret_cast<float4 *>(&in[0][0][0])[lane + 64 * k] = v[k];
+        FE_WAVE_SYNC();
+        x1 = &in[ch][0][sbnd * 18];                    // S[g-3]
+        x2 = &in[ch][1][sbnd * 18];                    // S[g-2]
     }
-    FE_WAVE_SYNC();
-    const float *x1 = &in[ch][0][sbnd * 18];    // S[g-3]
-    const float *x2 = &in[ch][1][sbnd * 18];    // S[g-2]
     float y[18], f[18];
     const bool act = sbnd < nsb;
     {
@@ -738,6 +757,14 @@ __global__ __launch_bounds__(128) void k_spec(const float *__restrict__ sb, cons
     }
     msmetric_unit(xl, xl + 576, p, T.mblog, msbase + sg, btype == 2, sb_start, sb_n);
 }
+
+#define HX_K4(name, direct) \
+__global__ __launch_bounds__(128) void name(const float *__restrict__ sb, const HxStream *__restrict__ st, const HxParams *__restrict__ prm, \
+                                           const HxGlobalTabs *__restrict__ gt, const unsigned char *__restrict__ bt, float *__restrict__ xr, \
+                                           float *__restrict__ etab_out, float *__restrict__ thr_out, int *__restrict__ msbase, int NG, int SG) \
+{ spec_granule<direct>(sb, st, prm, gt, bt, xr, etab_out, thr_out, msbase, NG, SG); }
+HX_K4(k_spec, false)
+HX_K4(k_spec_direct, true)
 
 // K5a: the frame's stereo decision (joint-stereo streams), serial per stream over its granules, and the hand-over
 // of the pre-echo memory between calls.  The L/R-vs-M/S metric of a granule gets a +-5000 hysteresis from the

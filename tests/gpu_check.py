@@ -37,7 +37,16 @@ def main():
     sr = kw.get("samprate", 44100)
     rhos = [0.7, 0.0, 1.0, 0.3]
     bursts = kw.get('short_block_threshold', 700) < 99999
-    pcm = np.stack([synth.stream_pcm(i, F, sr=sr, rho=rhos[i % 4], bursts=bursts) for i in range(S)])
+    seeds = list(range(S))
+    if "GC_KW" in os.environ:       # an arbitrary case: GC_KW='{"bitrate": 160, ...}' GC_SEEDS=395960 GC_RHO=0.7 GC_BURSTS=1 (stereo)
+        import json
+        kw = json.loads(os.environ["GC_KW"])
+        sr = kw.get("samprate", 44100)
+        seeds = [int(x) for x in os.environ.get("GC_SEEDS", "0").split(",")]
+        S = len(seeds)
+        rhos = [float(os.environ.get("GC_RHO", "0.7"))] * 4
+        bursts = bool(int(os.environ.get("GC_BURSTS", "0")))
+    pcm = np.stack([synth.stream_pcm(seeds[i], F, sr=sr, rho=rhos[i % 4], bursts=bursts) for i in range(S)])
     ec_o = O.default_control(**kw)
     ec_g = api.default_control(**kw)
     # oracle, with taps

@@ -516,6 +516,24 @@ def test_very_low_subband_limits(kw):
     b.close()
 
 
+@pytest.mark.parametrize("kw,seed,rho,F,cut,bursts", [
+    (dict(samprate=44100, mode=3, bitrate=160, hf_flag=3, nsbstereo=16, nsb_limit=28), 721109, 1.0, 12, 12, False),
+    (dict(samprate=44100, mode=0, bitrate=160, hf_flag=3, filter_select=1), 395960, 0.7, 120, 20, True)], ids=["mono_hf3_160k", "stereo_hf3_160k"])
+def test_band_21_lines_of_an_earlier_hf_pass_survive_the_rate_loop(kw, seed, rho, F, cut, bursts):
+    """-HF 3, L/R or mono granules: the rate loop's step towards more bits re-quantises without clearing band 21 (reference
+    bitallo3.cpp:2636-2668), so when the step drops the -HF quantisation the lines of the earlier pass stay in the buffer - out of the
+    counted range, except that the last quadruple reaches up to three lines into them.  The low-footprint kernel's quantiser wrote
+    zeros there (found by the round-4 sweep: 2 cases in 3000, first differing frame 16 and frame 1 of these two streams)."""
+    pcm = synth.stream_pcm(seed, F, sr=44100, rho=rho, bursts=bursts)[None, :cut * 1152]
+    if kw.get("mode") == 3:
+        pcm = np.ascontiguousarray(pcm[:, :, 0])
+    b = api().Batch(api().default_control(**kw), nstreams=1, max_frames=cut)
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    assert got[0] == oracle_bytes(kw, pcm[0], cut)
+    b.close()
+
+
 def test_reset_stream_starts_a_fresh_stream_in_a_running_batch():
     """hx_batch_reset_stream: a slot of a long-lived batch takes over a new input; its output equals a fresh encode
     of that input, and the neighbouring streams carry on undisturbed"""

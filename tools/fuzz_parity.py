@@ -111,7 +111,8 @@ while done < n_cases and tried < 20 * n_cases:
         enc = O.OracleEncoder(O.default_control(**kw))
         want = b"".join((enc.encode_f32 if as_f32 else enc.encode_s16)(pcm[s, f * 1152:(f + 1) * 1152]) for f in range(F))
         if got[s] != want or st != 0:
-            print("MISMATCH", kw, "stream", s, "seed", int(seeds[s]), "rho", float(rhos[s]), "amp", float(amp[s]), "status", st, len(got[s]), len(want), "f32" if as_f32 else "s16", "F", F)
+            nd = next((k for k in range(min(len(got[s]), len(want))) if got[s][k] != want[k]), min(len(got[s]), len(want)))
+            print("MISMATCH case", done, kw, "stream", s, "seed", int(seeds[s]), "rho", float(rhos[s]), "amp", float(amp[s]), "status", st, len(got[s]), len(want), "f32" if as_f32 else "s16", "F", F, "kind", kind, "first differing byte", nd, flush=True)
             bad += 1
             break
     done += 1
