@@ -1,5 +1,5 @@
 """Randomised parity sweep: random encoder controls x random synthetic streams, GPU batch (plain and submit path) against the
-CPU oracle.  python tools/fuzz_parity.py [n_cases] [seed].  Prints every mismatch; exit code 1 if there was one."""
+CPU oracle.  python tools/fuzz_parity.py [--a1 | --hf] [--submit] [n_cases] [seed].  Prints every mismatch; exit code 1 if there was one."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,9 @@ from oracle import oracle as O
 A1 = "--a1" in sys.argv                  # only configurations of the first-generation allocator (dual channel, low-rate joint stereo)
 if A1:
     sys.argv.remove("--a1")
+HF = "--hf" in sys.argv                  # only -HF configurations at MPEG-1 rates and high bit rates (band 21 gets quantised)
+if HF:
+    sys.argv.remove("--hf")
 SUBMIT = "--submit" in sys.argv          # random-sized calls through hx_batch_submit_s16_device (overlapped) instead of host calls
 if SUBMIT:
     sys.argv.remove("--submit")
@@ -34,6 +37,12 @@ while done < n_cases and tried < 20 * n_cases:
         kw["mode"] = mode = int(rs.choice([1, 2, 2]))
         kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40] if (mode == 1 or sr < 32000) else [16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
     if rs.rand() < 0.3: kw["hf_flag"] = int(rs.choice([1, 3]))
+    if HF:
+        kw["samprate"] = sr = int(rs.choice([32000, 44100, 48000]))
+        kw["hf_flag"] = int(rs.choice([1, 3, 3]))
+        kw.pop("vbr_mnr", None); kw.pop("bitrate", None)
+        if rs.rand() < 0.6: kw["bitrate"] = int(rs.choice([96, 112, 128, 160]))
+        else: kw["vbr_mnr"] = int(rs.randint(80, 151))
     if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000, 21000]))
     if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
     if rs.rand() < 0.15: kw["filter_select"] = 1
