@@ -1,4 +1,4 @@
-"""Long continuous streams: python tools/soak.py [frames] [cases] [streams]  - the first `cases` of six configurations (default
+"""Long continuous streams: python tools/soak.py [frames] [cases] [streams]  - the first `cases` of eight configurations (default
 all) x `streams` streams (default 6) x `frames` frames (default 20000) through calls of 1 .. 64 frames on one batch object,
 compared byte for byte with the oracle.  Exit code 1 on a difference.  (tests/test_gpu_runtime.py runs a slice: 6000 2 2)"""
 import sys, os
@@ -9,7 +9,7 @@ from oracle import oracle as O
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 CASES = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(samprate=22050, bitrate=32),
-         dict(bitrate=64, mode=3), dict(samprate=16000, mode=2, bitrate=16)]
+         dict(bitrate=64, mode=3), dict(samprate=16000, mode=2, bitrate=16), dict(mode=0, bitrate=160, hf_flag=3), dict(mode=3, bitrate=160, hf_flag=3)]
 CASES = CASES[:int(sys.argv[2])] if len(sys.argv) > 2 else CASES
 NS = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 bad = 0
