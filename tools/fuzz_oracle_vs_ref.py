@@ -1,5 +1,5 @@
 """Randomised pin of the oracle against the real reference (oracle/_ref; this container only): random controls x random
-signals, byte for byte.  python tools/fuzz_oracle_vs_ref.py [n_cases] [seed]"""
+signals, byte for byte.  python tools/fuzz_oracle_vs_ref.py [--a1 | --hf] [n_cases] [seed]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,9 @@ assert O.ref() is not None, "make -C oracle ref first"
 A1 = "--a1" in sys.argv        # only configurations of the first-generation allocator: dual channel, or joint stereo at low bit rates
 if A1:
     sys.argv.remove("--a1")
+HF = "--hf" in sys.argv        # only -HF configurations at MPEG-1 rates and high bit rates (band 21 gets quantised; tools/fuzz_parity.py --hf)
+if HF:
+    sys.argv.remove("--hf")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 RATES = [16000, 22050, 24000, 32000, 44100, 48000]
@@ -25,6 +28,12 @@ while done < n_cases and tried < 30 * n_cases:
         kw["mode"] = int(rs.choice([1, 2, 2]))
         kw["bitrate"] = int(rs.choice([8, 16, 24, 32, 40] if (kw["mode"] == 1 or sr < 32000) else [16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160]))
     if rs.rand() < 0.3: kw["hf_flag"] = int(rs.choice([1, 3]))
+    if HF:
+        kw["samprate"] = sr = int(rs.choice([32000, 44100, 48000]))
+        kw["hf_flag"] = int(rs.choice([1, 3, 3]))
+        kw.pop("vbr_mnr", None); kw.pop("bitrate", None)
+        if rs.rand() < 0.6: kw["bitrate"] = int(rs.choice([96, 112, 128, 160]))
+        else: kw["vbr_mnr"] = int(rs.randint(80, 151))
     if rs.rand() < 0.3: kw["freq_limit"] = int(rs.choice([8000, 12000, 16000, 19000, 21000]))
     if rs.rand() < 0.3: kw["short_block_threshold"] = int(rs.choice([300, 700, 2000, 99999]))
     if rs.rand() < 0.15: kw["filter_select"] = 1
