@@ -954,17 +954,54 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
         const int e = lane + 64 * k;
         unsigned bl = 0;
         if (e < 144) bl = reinterpret_cast<const unsigned *>(p->band_of_line)[e];       // the four lines' bands
+        // The band maximum of x^(3/4) is the x^(3/4) of the band's largest magnitude: the piecewise-linear fit is monotone
+        // over every non-negative float (checked exhaustively: tools/check_pow34_monotone.cpp).  So the lines contribute
+        // their magnitudes (sign bit off: lines past the magnitude range are raw, and the fit ignores the sign), and the
+        // band lane evaluates the fit once - 44 evaluations per granule instead of 1152.  The lines' own x^(3/4) is only
+        // formed for the tests' tap (the allocator's helper wave computes it for itself).
+        // A lane's four lines are two pairs, and a pair never straddles a band or the end of a coded range (bands start on even
+        // lines and have even widths): one LDS atomic per pair - per four lines when both pairs are in one band - instead of one
+        // per line.  (Atomics of a wave on one address are served one lane after the other: in a wide band that was up to 40
+        // passes per instruction, 24 instructions per lane.)
+        {
+            const int b0 = bl & 255, b2 = (bl >> 16) & 255, j0 = 4 * e, j2 = 4 * e + 2;
+            int m00 = max(__float_as_int(a0[k][0]) & 0x7FFFFFFF, __float_as_int(a0[k][1]) & 0x7FFFFFFF);
+            const int m02 = max(__float_as_int(a0[k][2]) & 0x7FFFFFFF, __float_as_int(a0[k][3]) & 0x7FFFFFFF);
+            int m10 = max(__float_as_int(a1[k][0]) & 0x7FFFFFFF, __float_as_int(a1[k][1]) & 0x7FFFFFFF);
+            const int m12 = max(__float_as_int(a1[k][2]) & 0x7FFFFFFF, __float_as_int(a1[k][3]) & 0x7FFFFFFF);
+            // (inside / outside the coded ranges: part of what makes a group - with -HF the range ends inside the last band's run
+            // of the line-to-band table, which maps everything above band 20 to band 21)
+            const int in0 = (j0 < nl_p0) | ((j0 < nl_p1) << 1), in2 = (j2 < nl_p0) | ((j2 < nl_p1) << 1);
+            const bool one = b0 == b2 && in0 == in2;
+            if (one) { m00 = max(m00, m02); m10 = max(m10, m12); }
+            // ... and per pair or four of neighbouring lanes whose lines lie in one band and on one side of the coded ranges' ends
+            // (they are then also all below line 576 or all above): the group's first lane brings the maximum of the group
+            bool issue = true;
+            {
+                const int key = one ? (b0 | (in0 << 8)) : -1 - lane;       // (a lane whose lines straddle two bands joins no group)
+#define PREP_QP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
+                const bool pair = PREP_QP(key, 0xB1) == key;                            // quad_perm [1,0,3,2]: the lane beside this one
+                if (pair) { m00 = max(m00, PREP_QP(m00, 0xB1)); m10 = max(m10, PREP_QP(m10, 0xB1)); }
+                const bool quad = pair && PREP_QP((int) pair, 0x4E) != 0 && PREP_QP(key, 0x4E) == key;      // quad_perm [2,3,0,1]: the other pair
+                if (quad) { m00 = max(m00, PREP_QP(m00, 0x4E)); m10 = max(m10, PREP_QP(m10, 0x4E)); }
+#undef PREP_QP
+                issue = quad ? (lane & 3) == 0 : (pair ? (lane & 1) == 0 : true);
+            }
+            if (issue && e < 144 && j0 < nl_p0) atomicMax(&xmax[wv][0][b0], m00);
+            if (issue && e < 144 && j0 < nl_p1) atomicMax(&xmax[wv][1][b0], m10);
+            if (!one) {
+                if (e < 144 && j2 < nl_p0) atomicMax(&xmax[wv][0][b2], m02);
+                if (e < 144 && j2 < nl_p1) atomicMax(&xmax[wv][1][b2], m12);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const int j = 4 * e + c, bnd = (bl >> (8 * c)) & 255;
+            const int j = 4 * e + c;
             q0[k][c] = q1[k][c] = 0.0f;
-            // The band maximum of x^(3/4) is the x^(3/4) of the band's largest magnitude: the piecewise-linear fit is monotone
-            // over every non-negative float (checked exhaustively: tools/check_pow34_monotone.cpp).  So the lines contribute
-            // their magnitudes (sign bit off: lines past the magnitude range are raw, and the fit ignores the sign), and the
-            // band lane evaluates the fit once - 44 evaluations per granule instead of 1152.  The lines' own x^(3/4) is only
-            // formed for the tests' tap (the allocator's helper wave computes it for itself).
-            if (e < 144 && j < nl_p0) { atomicMax(&xmax[wv][0][bnd], __float_as_int(a0[k][c]) & 0x7FFFFFFF); if (x34o) q0[k][c] = hx_pow34(t_a, t_b, t_exp, a0[k][c]); }
-            if (e < 144 && j < nl_p1) { atomicMax(&xmax[wv][1][bnd], __float_as_int(a1[k][c]) & 0x7FFFFFFF); if (x34o) q1[k][c] = hx_pow34(t_a, t_b, t_exp, a1[k][c]); }
+            if (x34o) {
+                if (e < 144 && j < nl_p0) q0[k][c] = hx_pow34(t_a, t_b, t_exp, a0[k][c]);
+                if (e < 144 && j < nl_p1) q1[k][c] = hx_pow34(t_a, t_b, t_exp, a1[k][c]);
+            }
         }
     }
     WAVE_SYNC();
