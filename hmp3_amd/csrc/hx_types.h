@@ -181,7 +181,12 @@ struct alignas(16) HxFrameOut {
 // k_polyphase (hx_front.hip) and its launch (hx_cabi.hip): granules per workgroup (252 of 256 lanes busy: a lane is a time slot
 // of a granule) and the workgroup size that follows.  One definition: the kernel's launch bounds, its LDS staging stride and
 // register array are sized by the same numbers the host launches with.
-#define K1_GPB 14
+// (7 granules: 126 of the workgroup's 128 lanes have a time slot, 37 KB of LDS, four workgroups per CU; with 14 - 252 of 256 lanes,
+// 70 KB, two per CU - the loads of one workgroup's tile overlapped less of the other's arithmetic: 7 is +1.6 % per step at configs 2
+// and 3; 3 and 5 granules are level with it, 10 in between)
+#ifndef K1_GPB
+#define K1_GPB 7
+#endif
 #define K1_THREADS ((K1_GPB * 18 + 63) / 64 * 64)
 
 // The lines' signs travel from k_prep (or, for short-block and first-generation-allocator granules, the stream walk) to
