@@ -143,7 +143,13 @@ struct hx_batch {
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
     bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
-    int lpt = 1;                        // longest-first workgroup order: 1 = for batches beyond the resident set, 0 = never, 2 = always (HMP3AMD_LPT; tests)
+    // longest-first workgroup order: 2 = always (default), 1 = only for batches beyond the resident set, 0 = never (HMP3AMD_LPT).
+    // Beyond the resident set it keeps the launch's last round short.  Within it the order decides which streams share a CU:
+    // workgroups are dealt over XCDs and CUs in turn, so a CU's four streams are 256 apart in launch order - in stream order
+    // those are streams of one residue class, and a batch whose slow streams recur with a period (BASELINE config 5: correlation
+    // by stream mod 4) had them all on the same CUs; sorted by the previous call's duration a CU gets one stream of each quartile.
+    // (Round 4: config 2 +1.0 %, its worst-case signal set +2.1 %.)
+    int lpt = 2;
 };
 
 extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
@@ -623,7 +629,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.done_counter = b->d_done;
     a.dur = b->d_dur;
     a.order = nullptr;
-    if ((S > b->resident && b->lpt) || b->lpt == 2) {       // more streams than resident workgroups: longest first
+    if ((S > b->resident && b->lpt) || b->lpt == 2) {       // longest first (see hx_batch::lpt)
         LAUNCH(k_order, dim3(1), dim3(1024), qa, (const unsigned *) b->d_dur, b->d_order, S);
         a.order = b->d_order;
     }
