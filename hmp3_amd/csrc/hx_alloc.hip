@@ -46,7 +46,8 @@ struct AllocPrm {
     struct { int npart; } psyS;
     int nchan, side_bytes;              // 1 / 17 for a mono stream (mode 3), 2 / 32 otherwise
     int is_flag, dual, npart_l;         // first-generation allocator: intensity part present, dual channel; long psy partitions
-    int oflags;                         // optional outputs of the call: 1 = packets, 2 = debug taps, 4 = per-frame counters
+    int oflags;                         // optional outputs of the call: 1 = packets, 2 = debug taps, 4 = per-frame counters, 8 = strict band sums everywhere
+    int run_w;                          // lines per lane of the certified band sums (HxParams::run_w)
 };
 
 // What the master wave hands to global memory in the frame loop - the k_pack records of a granule's channels and,
@@ -124,7 +125,9 @@ struct alignas(16) AllocLds {
     unsigned long long sgnbits[2][9];               // short blocks: sign of line t of channel c = bit t & 63 of word t >> 6
     ix_t ixsink;                                    // where the quantiser's store of a line it must leave alone goes
 #endif
-    unsigned char band_of_line[576];
+    unsigned char band_of_pair[288];                // sfb of lines 2 j, 2 j + 1 (bands start on even lines and have even widths)
+    unsigned short lane_run[64];                    // the lanes' line runs for the certified band sums (HxParams::lane_run)
+    unsigned char band_last[24];                    // last lane of each band's run of lanes
     // tables staged from global memory
     float look_ix43[256];
 #if !HX_SLIM
@@ -200,6 +203,7 @@ struct alignas(16) AllocLds {
     Outbox ob[2];
     const double *pow43;                // HxGlobalTabs::pow43 (global memory)
     int *big_counter;                   // device counter of line passes that took the double table (tests)
+    int nstrict;                        // certified band sums of this stream that fell back to the strict sum (added to big_counter[1] when the stream retires)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
     alignas(4) unsigned char gflag[HX_SLIM ? 64 : 256];     // block type | stereo decision << 2 of the next granules (frame loop, hx_alloc3.inc)
 #ifdef HX_PROFILE
@@ -236,6 +240,7 @@ __device__ __forceinline__ float lk_igain(const float *ig16, int g) { const int 
 #define LK_IGAIN_RAW(g) L.look_34igain[(g)]
 #define LK_IGAIN_FIN(raw, g) (raw)
 #endif
+#define BAND_OF_LINE(j) L.band_of_pair[(j) >> 1]
 
 #ifdef HX_PROFILE
 // (only the master wave's time is booked: the helper wave runs some of the same functions)
@@ -420,84 +425,107 @@ __device__ __forceinline__ bool noise_band_needs_pow(float igain, float x34max)
     return (int) (tmp + copysignf(0.5f, tmp)) >= 256;
 }
 
-// Line operands of the gain search, held in registers for a whole seek_actual call: lane l owns
-// lines l, l+64, ... l+512 of both channels (x, x^(3/4), and the line's sfb).
-// (one channel per wave: the master keeps channel 0, the helper wave channel 1)
-struct SweepRegs { float x34[9], xr[9]; int bnd[9]; };
+// Line operands of the gain search, held in registers for a whole seek_actual call: lane l owns a run of up to run_w
+// consecutive lines of one band (x and x^(3/4); hx_dev.h, "certified band sums"); lines past the run's end are zeros,
+// whose noise term is +0.  (one channel per wave: the master keeps channel 0, the helper wave channel 1)
+#define RUNW_MAX 10
+struct SweepRegs { float x34[RUNW_MAX], xr[RUNW_MAX]; };
+struct LaneRun { int start, cnt, d, band; };    // this lane's run: first line, lines, lanes back to the band's first lane, the band
 
-__device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R, int ch)
+__device__ __forceinline__ LaneRun lane_run(const AllocLds &L)
 {
     HX_LANE_DECL;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int j = LANE + 64 * k;
-        R.bnd[k] = L.band_of_line[j];
-        R.x34[k] = L.x34[ch][j];
-        R.xr[k] = L.xr[ch][j];
-    }
+    const unsigned r = L.lane_run[LANE];
+    LaneRun q;
+    q.start = (int) (r & 511u) << 1; q.cnt = (int) ((r >> 9) & 7u) << 1; q.d = (int) (r >> 12);
+    q.band = L.band_of_pair[r & 511u];
+    return q;
 }
 
-// Noise terms of one channel's lines [lo, nl) for the gain pairs published in L.gpair.
-// Chunks of three lines per lane (192 lines per chunk, chunks outside the evaluated range are
-// skipped): per line one gain-pair read, one table read, one store.  All loads of a chunk
-// come before its stores (an LDS store in between would pin the later loads behind it: the
-// compiler cannot tell the tables from the term buffer).  Lines of bands that are not being
-// evaluated get a meaningless term, which nobody reads - cheaper than predicating the store.
-__device__ __forceinline__ void sweep_lines(AllocLds &L, const SweepRegs &R, int ch, int lo, int nl)
+__device__ __forceinline__ void sweep_load(const AllocLds &L, SweepRegs &R, const LaneRun &q, int W, int ch)
 {
-    HX_LANE_DECL;
 #pragma unroll
-    for (int c3 = 0; c3 < 3; c3++) {
-        if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
-        float t[3];
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int k = 3 * c3 + k3;
-            const float2 gp = L.gpair[ch][R.bnd[k]];
-            t[k3] = noise_term_fast(L, gp.x, gp.y, R.x34[k], R.xr[k]);
+    for (int k = 0; k < RUNW_MAX; k += 2) {
+        float2 a = make_float2(0.0f, 0.0f), b = make_float2(0.0f, 0.0f);
+        if (k < W) {
+            // (a run never ends inside a pair; a read past the run stays inside the LDS block and is dropped)
+            a = *reinterpret_cast<const float2 *>(&L.x34[ch][q.start + k]);
+            b = *reinterpret_cast<const float2 *>(&L.xr[ch][q.start + k]);
+            if (k >= q.cnt) { a = make_float2(0.0f, 0.0f); b = a; }
         }
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
+        R.x34[k] = a.x; R.x34[k + 1] = a.y; R.xr[k] = b.x; R.xr[k + 1] = b.y;
     }
 }
 
-// The same sweep when some evaluated band may quantise beyond the float table (decided per sweep from the band
-// maxima; loud near-mono material at low gain steps): terms beyond the table come from the double table.  Out of
-// line and from LDS instead of the caller's registers, three lines at a time, so that the rare case costs the common
-// path neither registers nor code.  (Bands that are not evaluated quantise to <= 0.)
-__device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl)
+// The lane's share of a band's noise: terms of its run for the band's published gain pair, added up (tree of pairs).
+__device__ __forceinline__ float sweep_run(const AllocLds &L, const SweepRegs &R, const LaneRun &q, int W, int ch)
+{
+    const float2 gp = L.gpair[ch][q.band];
+    float t[RUNW_MAX];
+#pragma unroll
+    for (int k = 0; k < RUNW_MAX; k += 2) {
+        t[k] = t[k + 1] = 0.0f;
+        if (k < W) {
+            t[k] = noise_term_fast(L, gp.x, gp.y, R.x34[k], R.xr[k]);
+            t[k + 1] = noise_term_fast(L, gp.x, gp.y, R.x34[k + 1], R.xr[k + 1]);
+        }
+    }
+    return (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) + (t[8] + t[9]);
+}
+
+// The same from LDS, with the terms also stored in line order (L.term) for a lane that has to add a band strictly, and
+// terms beyond the 256-entry table taken from the double table (loud near-mono material at low gain steps; decided per
+// sweep from the band maxima).  Out of line: the rare cases cost the common path neither registers nor code.
+// (Bands that are not evaluated quantise to <= 0; count: book the pass in the double-table counter.)
+__device__ __noinline__ float sweep_run_stored(AllocLds &L, int ch, int W, int count)
 {
     HX_LANE_DECL;
-    if (LANE == 0) atomicAdd(L.big_counter, 1);
+    if (count && LANE == 0) atomicAdd(L.big_counter, 1);
+    const LaneRun q = lane_run(L);
+    const float2 gp = L.gpair[ch][q.band];
+    float acc = 0.0f;
 #pragma unroll 1
-    for (int c3 = 0; c3 < 3; c3++) {
-        if (192 * c3 >= nl || 192 * c3 + 192 <= lo) continue;
-        float t[3], gn[3], xr[3];
-        int qx[3];
-        double pw[3];
+    for (int k = 0; k < W; k += 2) {
+        float t[2], xr[2];
+        int qx[2];
+        const float2 a = *reinterpret_cast<const float2 *>(&L.x34[ch][q.start + k]);
+        const float2 b = *reinterpret_cast<const float2 *>(&L.xr[ch][q.start + k]);
+        const bool in = k < q.cnt;
+        const float x34[2] = {in ? a.x : 0.0f, in ? a.y : 0.0f};
+        xr[0] = in ? b.x : 0.0f; xr[1] = in ? b.y : 0.0f;
 #pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) {
-            const int j = LANE + 64 * (3 * c3 + k3), bnd = L.band_of_line[j];
-            const float2 gp = L.gpair[ch][bnd];
-            const float ig = gp.x, x34 = L.x34[ch][j];
-            gn[k3] = gp.y;
-            xr[k3] = L.xr[ch][j];
-            const float tmp = (ig * x34 + (0.0f - 0.0946f));
-            qx[k3] = (int) (tmp + copysignf(0.5f, tmp));
-            t[k3] = noise_term_fast(L, ig, gn[k3], x34, xr[k3]);
+        for (int e = 0; e < 2; e++) {
+            const float tmp = (gp.x * x34[e] + (0.0f - 0.0946f));
+            qx[e] = (int) (tmp + copysignf(0.5f, tmp));
+            t[e] = noise_term_fast(L, gp.x, gp.y, x34[e], xr[e]);
         }
-        // (a chunk none of whose 192 lines quantises beyond the float table - the loud lines sit in a few low bands - does not
-        // go to the double table at all: its memory round trip is most of this pass)
-        if (__any(qx[0] >= 256 || qx[1] >= 256 || qx[2] >= 256)) {
+        // (a pass none of whose lines quantises beyond the float table - the loud lines sit in a few low bands - does not
+        // go to the double table at all: its memory round trip is most of this function)
+        if (__any(qx[0] >= 256 || qx[1] >= 256)) {
+            double pw[2];
 #pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) pw[k3] = L.pow43[min(max(qx[k3], 0), HX_POW43_N - 1)];
+            for (int e = 0; e < 2; e++) pw[e] = L.pow43[min(max(qx[e], 0), HX_POW43_N - 1)];
 #pragma unroll
-            for (int k3 = 0; k3 < 3; k3++)
-                if (qx[k3] >= 256) { const float d = xr[k3] - noise_xhat_big(L, qx[k3], pw[k3], gn[k3]); t[k3] = d * d; }
+            for (int e = 0; e < 2; e++)
+                if (qx[e] >= 256) { const float d = xr[e] - noise_xhat_big(L, qx[e], pw[e], gp.y); t[e] = d * d; }
         }
-#pragma unroll
-        for (int k3 = 0; k3 < 3; k3++) L.term[ch][LANE + 64 * (3 * c3 + k3)] = t[k3];
+        if (in) *reinterpret_cast<float2 *>(&L.term[ch][q.start + k]) = make_float2(t[0], t[1]);
+        acc += (t[0] + t[1]);
     }
+    return acc;
+}
+
+// A band whose certified interval straddles a bucket boundary of mbLogC (a few per cent of the sweeps have one): its lane
+// adds the band's terms in line order.  have_terms: the terms are in L.term already (the double-table pass stores them).
+__device__ __noinline__ float sweep_sum_strict(AllocLds &L, int ch, int W, int have_terms, bool need, int sbeg, int n, float fast)
+{
+    HX_LANE_DECL;
+    if (!have_terms) (void) sweep_run_stored(L, ch, W, 0);
+    SYNC();
+    if (LANE == 0) atomicAdd(&L.nstrict, 1);
+    float sxx = fast;
+    if (need) sxx = band_sum(&L.term[ch][sbeg], n, 0.0f);
+    return sxx;
 }
 
 // One sweep of the gain search for channel ch, run by one wave on its own (the master wave does
@@ -506,13 +534,12 @@ __device__ __noinline__ void sweep_lines_big(AllocLds &L, int ch, int lo, int nl
 // passes the gain step g it wants measured (-1: none) and gets the band's noise back in a register;
 // sbeg / send are the lane's band limits, kept by the caller.
 // (ig, gn = the step's gain pair 1 / gain^(3/4), gain: the caller reads the tables a sweep ahead, see seek_actual_ch;
-// x34max, logcbw = the band lane's constants, kept by the caller)
-__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int ch, int g, float ig_g, float gn_g, float x34max, int logcbw, int sbeg, int send, int nlines)
+// x34max, logcbw = the band lane's constants, kept by the caller; q, W: the lane's run; du, last4: the band lane's interval
+// half-width and 4 x the last lane of its band's run of lanes)
+__device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, const LaneRun &q, int W, int ch, int g, float ig_g, float gn_g, float x34max, int logcbw, int sbeg, int send, float du, int last4)
 {
     HX_LANE_DECL;
     // band lanes publish the gain pair of their evaluation step (igain < 0: band not evaluated)
-    // and the line range that any evaluated band touches: the bands lie in lane order, so it runs from the first
-    // evaluated band's start to the last one's end (two lane reads instead of two wave reductions)
     bool bslow = false;
     PROF_T0();
     if (LANE < NB) {
@@ -520,24 +547,20 @@ __device__ __forceinline__ int noise_sweep(AllocLds &L, const SweepRegs &R, int 
         L.gpair[ch][LANE] = make_float2(ig, (g >= 0) ? gn_g : 0.0f);
         if (g >= 0) bslow = noise_band_needs_pow(ig, x34max);
     }
-    const unsigned long long evald = __ballot(LANE < NB && g >= 0);
-    int lo = 576, hi = 0;
-    if (evald) {
-        lo = __builtin_amdgcn_readlane(sbeg, __builtin_ctzll(evald));
-        hi = __builtin_amdgcn_readlane(send, 63 - __builtin_clzll(evald));
-    }
     SYNC();
     PROF_ACC(27);
-    const int nl = min(nlines, hi);
-    if (__builtin_expect(__any(bslow), 0)) sweep_lines_big(L, ch, lo, nl);
-    else sweep_lines(L, R, ch, lo, nl);
-    SYNC();
+    const int anyslow = __any(bslow) ? 1 : 0;
+    float part;
+    if (__builtin_expect(anyslow, 0)) part = sweep_run_stored(L, ch, W, 1);
+    else part = sweep_run(L, R, q, W, ch);
     PROF_ACC(28);
+    // the band's total arrives in its last lane; the band lane fetches it and certifies the bucket
+    float sxx = hx_lane_read(last4, hx_seg_scan(part, q.d, LANE));
+    bool strict = false;
+    if (g >= 0) strict = du < 0.0f || !hx_cert_mblog(sxx, du);
+    if (__builtin_expect(__any(strict), 0)) sxx = sweep_sum_strict(L, ch, W, anyslow, strict, sbeg, send - sbeg, sxx);
     int noise = 0;
-    if (g >= 0) {
-        const float sxx = band_sum(&L.term[ch][sbeg], send - sbeg, 0.0f);
-        noise = MBLOG(1.0e-12f + sxx) - logcbw;
-    }
+    if (g >= 0) noise = MBLOG(1.0e-12f + sxx) - logcbw;
     SYNC();
     PROF_ACC(29);
     return noise;
@@ -678,8 +701,9 @@ HX_SEEK_INLINE void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
         else { smin = L.gzero[ch][i] + 5; tnmin = L.Noise0[ch][i]; }
     }
     SweepRegs R;
-    const int nl = p->nbmax[ch];
-    sweep_load(L, R, ch);
+    const int W = p->run_w;
+    const LaneRun q = lane_run(L);
+    sweep_load(L, R, q, W, ch);
     // The gain pair of a step comes from two tables in LDS.  A walking band's next step is known before the current
     // one is measured (one down or one up), so its pair is read a sweep ahead and the sweep starts without that
     // round trip; the first measurement reads both neighbours.  (Indices are clamped for the reads only: a step
@@ -687,6 +711,9 @@ HX_SEEK_INLINE void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
     const int ib = min(i, NB - 1);
     const float x34max = L.x34max[ch][ib];
     const int logcbw = L.logcbw[ib];
+    // the band lane's interval half-width (strict sums everywhere: no interval passes) and where its band's total arrives
+    const float du = (p->oflags & 8) ? -1.0f : hx_cert_delta(send - sbeg, W);
+    const int last4 = 4 * (int) L.band_last[ib];
     float ig_c = LK_IGAIN(s & 127), gn_c = LK_GAIN(s & 127);      // pair of the step to measure now
     float ig_dn = 0.0f, gn_dn = 0.0f, ig_up = 0.0f, gn_up = 0.0f;          // pairs of the steps below / above it
     SYNC();
@@ -700,7 +727,7 @@ HX_SEEK_INLINE void seek_actual_ch(AllocLds &L, const AllocPrm *p, int ch)
         const int gdn = max(max(gcur, 0) - 1, 0), gup = min(max(gcur, 0) + 1, 127);
         if (mode != 3) { ig_dn = LK_IGAIN_RAW(gdn); gn_dn = LK_GAIN_RAW(gdn); }
         if (mode != 2) { ig_up = LK_IGAIN_RAW(gup); gn_up = LK_GAIN_RAW(gup); }
-        const int noise = noise_sweep(L, R, ch, gcur, ig_c, gn_c, x34max, logcbw, sbeg, send, nl);
+        const int noise = noise_sweep(L, R, q, W, ch, gcur, ig_c, gn_c, x34max, logcbw, sbeg, send, du, last4);
         if (mode == 1) {
             const int dn = noise - NTarget;
             ntadj += (dn >> 3);
@@ -858,7 +885,7 @@ __device__ __forceinline__ void lucky_terms(AllocLds &L, int nl, int ncmax, floa
         const int cc = (ok && t >= nl) ? 1 : 0, j = ok ? t - (cc ? nl : 0) : 0;
         sx34[q] = L.x34[cc][j];
         sxr[q] = L.xr[cc][j];
-        sg[q] = max(L.geval[cc][L.band_of_line[j]], 0);
+        sg[q] = max(L.geval[cc][BAND_OF_LINE(j)], 0);
         ssd[q] = 2 * (1 + L.scale[cc]);
         base[q] = ok ? &tf[t] : LANE_SINK;
         stride[q] = ok ? 2 * nl : 0;
@@ -896,7 +923,7 @@ __device__ __noinline__ void lucky_terms_big(AllocLds &L, int nl, int ncmax, flo
         const int cc = (ok && t >= nl) ? 1 : 0, j = ok ? t - (cc ? nl : 0) : 0;
         sx34[q] = L.x34[cc][j];
         sxr[q] = L.xr[cc][j];
-        sg[q] = max(L.geval[cc][L.band_of_line[j]], 0);
+        sg[q] = max(L.geval[cc][BAND_OF_LINE(j)], 0);
         ssd[q] = 2 * (1 + L.scale[cc]);
         base[q] = ok ? &tf[t] : LANE_SINK;
         stride[q] = ok ? 2 * nl : 0;
@@ -1048,7 +1075,7 @@ __device__ __forceinline__ void quant_lines(AllocLds &L, const AllocPrm *p, int 
 #endif
     int q[9], b[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) b[k] = L.band_of_line[LANE + 64 * k];
+    for (int k = 0; k < 9; k++) b[k] = BAND_OF_LINE(LANE + 64 * k);
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const int j = LANE + 64 * k;

@@ -134,7 +134,7 @@ struct hx_batch {
     long long nhost = 0;
     unsigned *d_dur = nullptr;          // [S] duration of each stream's allocator workgroup in the last launch
     int *d_order = nullptr;             // [S] workgroup -> stream for the next launch (used when the batch exceeds what the chip holds at once)
-    int *d_done = nullptr;              // [0] streams retired, [2] streams started by all k_alloc launches of this batch (wrap), [1] gate time-outs, [3] line passes on the double x^(4/3) table
+    int *d_done = nullptr;              // [0] streams retired, [2] streams started by all k_alloc launches of this batch (wrap), [1] gate time-outs, [3] line passes on the double x^(4/3) table, [4] certified band sums that fell back to the strict sum
     int resident = 0;                   // allocator workgroups the device holds at once
     long long alloc_launches = 0;
     unsigned long long cfg_hash = 0;    // fingerprint of the resolved configuration classes (checkpoint blobs carry their stream's)
@@ -150,6 +150,7 @@ struct hx_batch {
     // by stream mod 4) had them all on the same CUs; sorted by the previous call's duration a CU gets one stream of each quartile.
     // (Round 4: config 2 +1.0 %, its worst-case signal set +2.1 %.)
     int lpt = 2;
+    int strict_sums = 0;                // HMP3AMD_EXACT_SUMS=1: the stream walk adds every band in line order instead of certifying a parallel sum (tests)
 };
 
 extern "C" const char *hx_last_error(void) { return g_err.c_str(); }
@@ -279,12 +280,13 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_status, sizeof(int));
     ALLOC(b->d_outbytes, sizeof(int) * S);
     if (const char *e = getenv("HMP3AMD_LPT")) b->lpt = atoi(e);
+    if (const char *e = getenv("HMP3AMD_EXACT_SUMS")) b->strict_sums = atoi(e) != 0;
     ALLOC(b->d_lens, sizeof(int) * 4 * S);
     ALLOC(b->d_dur, sizeof(unsigned) * S);
     ALLOC(b->d_order, sizeof(int) * S);
     HIPCHKN(hipMemset(b->d_dur, 0, sizeof(unsigned) * S));
-    ALLOC(b->d_done, 4 * sizeof(int));
-    HIPCHKN(hipMemset(b->d_done, 0, 4 * sizeof(int)));
+    ALLOC(b->d_done, 8 * sizeof(int));
+    HIPCHKN(hipMemset(b->d_done, 0, 8 * sizeof(int)));
     {
         hipDeviceProp_t prop;
         int per_cu = 0;
@@ -627,6 +629,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.dbg = b->debug ? b->d_dbg : nullptr; a.out_stride = out_stride; a.NG = NG; a.S = S; a.status = b->d_status; a.prof = b->d_prof;
     a.packet = b->pk_buf; a.packet_stride = b->pk_stride; a.packet_bytes = b->pk_bytes; a.frame_stats = b->frame_stats;
     a.done_counter = b->d_done;
+    a.strict_sums = b->strict_sums;
     a.dur = b->d_dur;
     a.order = nullptr;
     if ((S > b->resident && b->lpt) || b->lpt == 2) {       // longest first (see hx_batch::lpt)
@@ -975,6 +978,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }
     else if (k == "dur") { src = b->d_dur; n = sizeof(unsigned) * S; }              // the last allocator launch's per-stream durations, 100 MHz ticks
     else if (k == "big_sweeps") { src = b->d_done + 3; n = sizeof(int); }        // gain-search line passes that took the double x^(4/3) table
+    else if (k == "strict_sums") { src = b->d_done + 4; n = sizeof(int); }       // certified band sums that fell back to the strict line-order sum
     else if (k == "bt") { src = b->d_bt; n = S * NG; }
     else if (k == "eng") { src = b->d_eng; n = sizeof(int) * S * 2 * NG * 9; }
     else if (k == "dbg" && b->d_dbg) { src = b->d_dbg; n = sizeof(HxFrameDebug) * S * (NG / 2); }
@@ -1022,7 +1026,10 @@ extern "C" long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *nam
     TAB("anwin", g.anwin) TAB("mblog", g.mblog) TAB("mbexp_lo", g.mbexp_lo) TAB("mbexp_hi", g.mbexp_hi)
     TAB("pow34_exp", g.pow34_exp) TAB("quant_off", g.quant_off) TAB("logsub", g.logsub)
     TAB("huff_code", g.huff_code) TAB("huff_len", g.huff_len)
+    TAB("lane_run", p.lane_run) TAB("band_last_lane", p.band_last_lane) TAB("lucky_run", p.lucky_run) TAB("lucky_last", p.lucky_last)
+    TAB("nchan", p.nchan)
 #undef TAB
+    if (k == "run_w") { static int v[2]; v[0] = p.run_w; v[1] = p.lucky_w; src = v; n = sizeof(v); }
     if (k == "scalars") {
         static int v[16];
         v[0] = p.nsb_limit; v[1] = p.nsb_ms0; v[2] = p.band_limit; v[3] = p.main_framebytes; v[4] = p.AveTargetBits;

@@ -103,6 +103,53 @@ __device__ __forceinline__ float hx_pow34(const float *a, const float *b, const 
     return (m * b[seg] + a[seg]) * ex[e];
 }
 
+// ---- certified band sums -------------------------------------------------------------------------------------
+// The reference adds a band's non-negative terms t_0 .. t_(n-1) left to right in fp32 (l3math.c:521-537) and hands the
+// sum s to mbLogC (l3math.c:228-242), which reads only its exponent and top 8 mantissa bits.  Any other fp32 summation
+// order t of the same terms, every term passing through at most D additions, satisfies
+//     |s - S| <= ((1 + u)^(n-1) - 1) S,   |t - S| <= ((1 + u)^D - 1) S      (S the exact sum, u = 2^-24; no underflow
+// in fp32 addition), hence s lies in [t (1 - c u), t (1 + c u)] for c = n + D + slack.  1.0e-12f + x and the bucket
+// (bits >> 15) are monotone in x: if both ends of the interval land in the same bucket, the reference's mbLogC value is
+// proven without forming s; otherwise the band's lane adds the terms in line order as before.  The same holds for the
+// quotient of two such sums (inverse_sf2) with the interval of the quotient.  tests/test_cert_sums.py checks the bound on
+// 10^6 random and adversarial term vectors against the strict sum; HMP3AMD_EXACT_SUMS=1 forces the strict sum everywhere.
+//
+// Layout: the 64 lanes each own a run of at most W consecutive lines of one band (HxParams::lane_run), add their own terms,
+// and a segmented inclusive scan over the neighbouring lanes of a band (at most 16, d = lanes back to the band's first one)
+// leaves the band's total in its last lane: row_shr 1/2/4/8 inside the 16-lane rows, then the previous row's last lane
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into row 2) for a band that straddles a row boundary.
+// Depth of a term: (W - 1) + 6 additions.
+#define HX_DPPF(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ float hx_seg_scan(float v, int d, int lane)
+{
+    float t;
+    t = HX_DPPF(v, 0x111, 0xf); v += (d >= 1) ? t : 0.0f;
+    t = HX_DPPF(v, 0x112, 0xf); v += (d >= 2) ? t : 0.0f;
+    t = HX_DPPF(v, 0x114, 0xf); v += (d >= 4) ? t : 0.0f;
+    t = HX_DPPF(v, 0x118, 0xf); v += (d >= 8) ? t : 0.0f;
+    const bool cross = d > (lane & 15);         // the band's first lane is in the row before this one
+    t = HX_DPPF(v, 0x142, 0xa); v += cross ? t : 0.0f;
+    t = HX_DPPF(v, 0x143, 0x4); v += cross ? t : 0.0f;
+    return v;
+}
+// the value of lane src4 / 4 (LDS crossbar, no memory access)
+__device__ __forceinline__ float hx_lane_read(int src4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); }
+// c u for a band of n terms summed in runs of W: n - 1 + (W - 1 + 6) roundings, + 12 for the second-order terms and the
+// roundings of the interval's own arithmetic
+__device__ __forceinline__ float hx_cert_delta(int n, int W) { return (float) (n + W + 16) * 5.9604644775390625e-08f; }
+// do both ends of [t (1 - du), t (1 + du)], after the reference's + 1.0e-12f, fall into one mbLogC bucket?
+__device__ __forceinline__ bool hx_cert_mblog(float t, float du)
+{
+    const float e = t * du;
+    return (hx_f2bits(1.0e-12f + (t - e)) >> 15) == (hx_f2bits(1.0e-12f + (t + e)) >> 15);
+}
+// the same for mbLogC(x / q) of two certified sums (IEEE division: monotone in both arguments)
+__device__ __forceinline__ bool hx_cert_mblog_ratio(float x, float q, float du)
+{
+    const float ex = x * du, eq = q * du;
+    return (hx_f2bits((x - ex) / (q + eq)) >> 15) == (hx_f2bits((x + ex) / (q - eq)) >> 15);
+}
+
 // sequential (reference-order) sum of term[ch][start .. start+n)
 // Every scalefactor band starts on an even line and has an even width (ISO Table B.8), so the
 // terms are fetched as 8-byte pairs, four pairs in flight, and added strictly in line order.

@@ -49,6 +49,14 @@ struct HxParams {
     int look_log_cbwmb[22];
     float rnBand_l[22];
     unsigned char band_of_line[576];    // sfb index of each MDCT line (allocator's band table)
+    // Blocked line runs of the stream walk's certified band sums (hx_alloc.hip, noise_sweep / inverse_sf2; hx_host.cpp band_runs):
+    // lane l owns up to run_w consecutive lines of ONE band among the bands the gain search measures, the lanes of a band are
+    // neighbours (at most 16).  lane_run[l] = first line >> 1 | (lines >> 1) << 9 | (lanes between l and its band's first lane) << 12;
+    // band_last_lane[b] = the last lane of band b's run of lanes.  The same for big_lucky_noise's bands 0..12 of both channels
+    // (lucky_w, lucky_run: channel << 15 | lanes to the band's first << 12 | (lines >> 1) << 9 | first line >> 1; lucky_last[ch][b]).
+    int run_w, lucky_w;
+    unsigned short lane_run[64], lucky_run[64];
+    unsigned char band_last_lane[24], lucky_last[2][16];
     // 32-point analysis DCT: twiddles 2 cos(pi (2j+1) / 2N) of the size-N step at [N/2 + j] (heap order; [0] unused)
     float dct_tw[32];
     float win[4][36], csa[2][8];
@@ -218,7 +226,8 @@ struct AllocArgs {
     int *pre_len, *carry_len;   // [S] bytes of pending frames' images at the call's start (k_pack_pre copies them in) / at its end (k_pack_carry saves them)
     const int *order;           // workgroup -> stream (longest-running first, from the previous call's durations), or null = identity
     unsigned *dur;              // [S] this call's duration of each stream's workgroup, 100 MHz ticks
-    int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter)
+    int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter), [3] double-table line passes, [4] certified band sums that fell back to the strict sum
+    int strict_sums;            // 1 = no certified band sums: every band is added in line order (HMP3AMD_EXACT_SUMS=1; tests)
     // from k_msscan / k_prep (hx_front.hip); xr holds the coded magnitudes for long-block granules
     const float *x34;           // [S][NG][2][576] x^(3/4) of the magnitudes (long-block granules)
     const unsigned *sgn;        // [S][NG][2][HX_SGN_WORDS] sign of each line, one bit per line in line order (bit j & 31 of word j >> 5)
