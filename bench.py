@@ -286,7 +286,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed pass on the correlation-cycled signal set (config 2, one GPU)")
     ap.add_argument("--host-fed", type=int, default=-1, help="1 / 0: also time (or not) the workload fed from page-locked host memory through the pipelined host-buffer calls; default: config 2 only")
-    ap.add_argument("--other-configs", type=int, default=-1, help="1 / 0: also run BASELINE configs 3, 4 and 5 at full width for 4 timed steps each and append them as other_configs; default: with config 2 on one GPU at its own size")
+    ap.add_argument("--other-configs", type=int, default=-1, help="1 / 0: also run the other BASELINE configs at full width for 4 timed steps each and append them as other_configs (one GPU: 3, 4, 5; several: 4 and 5, the configs BASELINE defines on 8 GPUs), each with its host-fed rate; default: with config 2 at its own size")
+    ap.add_argument("--strong-scaling", type=int, default=-1, help="1 / 0: with --gpus N > 1 also time config 2's 1024 streams split N ways (strong scaling, SURVEY 8e); default: with config 2 at its own size")
     ap.add_argument("--no-pipeline", action="store_true", help="plain hx_batch_encode_s16_device calls instead of submit / wait")
     ap.add_argument("--gate", type=int, default=-1, help="hx_batch_set_gate percent (library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the barrier / max-time (nccl = RCCL)")
@@ -294,9 +295,15 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="rendezvous, sharding and reporting only, no encode (CPU test of the multi-rank path)")
     args = ap.parse_args()
     if args.other_configs < 0:
-        args.other_configs = 1 if (args.config == 2 and args.gpus == 1) else 0
+        args.other_configs = 1 if args.config == 2 else 0
+    if args.strong_scaling < 0:
+        args.strong_scaling = 1 if (args.config == 2 and args.gpus > 1 and not args.streams and not args.frames) else 0
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    # what the line will carry beside `value` (also printed by --dry-run, so that the multi-rank CPU tests can check the plan)
+    plan_other = [c for c in ((3, 4, 5) if args.gpus == 1 else (4, 5)) if c != args.config] if (args.other_configs and not args.streams and not args.frames) else []
+    plan = {"other_configs": plan_other, "host_fed_configs": ([args.config] if (args.host_fed == 1 or (args.host_fed < 0 and args.config == 2)) else []) + (plan_other if args.host_fed != 0 else []),
+            "strong_scaling": bool(args.strong_scaling and args.gpus > 1), "worst_case": bool(args.config == 2 and args.gpus == 1 and not args.no_worst_case)}
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -351,7 +358,8 @@ def main():
             dist.all_gather_object(blocks, mine)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int((seen > 0).sum()), "streams_total": int(seen.sum()),
-                              "max_time_token": float(t.item()), "blocks": blocks, "nclasses": ncls, "rho_cycle": wl["rho"],
+                              "max_time_token": float(t.item()), "blocks": blocks, "nclasses": ncls, "rho_cycle": wl["rho"], "plan": plan,
+                              "strong_scaling_blocks": [list(shard.shard_range(workload(2)["S"], world, r)) for r in range(world)] if plan["strong_scaling"] else None,
                               "config": {"workload": wl["name"] % (S, F), "baseline_config": args.config}}), flush=True)
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
@@ -445,11 +453,12 @@ def main():
         del out, nbytes, outs, nbs
         return m
 
-    def run_host_fed(pcm):
+    def run_host_fed(pcm, c=None, steps_h=None):
         """The same workload fed from host memory: page-locked PCM in, bitstream out, through the pipelined host-buffer
         entry points (hx_batch_submit_s16_host / hx_batch_wait_host: the PCM of call n+1 and the bitstream of call n-1
-        cross PCIe while call n is encoded).  Reported next to `value`, never as it."""
-        steps_h = max(2, min(args.steps, 8))
+        cross PCIe while call n is encoded).  Reported next to `value`, never as it.  (c: another configuration's set-up)"""
+        S, F, kws, ncls = (c["S"], c["F"], c["kws"], c["ncls"]) if c else (S0, F0, kws0, ncls0)
+        steps_h = steps_h or max(2, min(args.steps, 8))
         ctl = api.default_control(**kws[0]) if ncls == 1 else [api.default_control(**k) for k in kws]
         batch = api.Batch(ctl, nstreams=S, max_frames=F, device=local)
         stride = batch.out_stride(F)
@@ -470,7 +479,10 @@ def main():
         t0 = time.perf_counter()
         go(steps_h)
         dt = time.perf_counter() - t0
-        placement["host_fed_ms_per_step"] = round(dt / steps_h * 1e3, 3)       # this rank's own time (the line's value uses the slowest rank's)
+        if c is None:
+            placement["host_fed_ms_per_step"] = round(dt / steps_h * 1e3, 3)       # this rank's own time (the line's value uses the slowest rank's)
+        else:
+            placement.setdefault("host_fed_ms_per_step_other", {})[str(c["cfg"])] = round(dt / steps_h * 1e3, 3)
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -478,6 +490,7 @@ def main():
         st = batch.status()
         used = int(nbs[(steps_h - 1) & 1].sum().item())
         batch.close()
+        del outs, nbs
         return {"value": round(S * F * steps_h * world / dt, 1), "unit": "frames/s", "steps": steps_h, "ms_per_step": round(dt / steps_h * 1e3, 3),
                 "h2d_GBps": round(hp.numel() * 2 * steps_h / dt / 1e9, 2), "d2h_GBps": round(S * stride * steps_h / dt / 1e9, 2),
                 "bytes_per_step": {"pcm_in": int(hp.numel() * 2), "out_buffer": int(S * stride), "bitstream_used": used}, "kernel_status": st,
@@ -499,22 +512,43 @@ def main():
     del pcm
     # ---- the other BASELINE configurations at full width, a few steps each: reported beside `value`, never as it ----
     others = []
-    if args.other_configs and not args.streams and not args.frames:
-        for cfg in (3, 4, 5):
-            if cfg == args.config:
-                continue
-            c = config_setup(cfg)
-            pcm = synth_batch_gpu(torch, np, c["S"], c["F"], c["srs"], c["rhos"], c["wl"]["bursts"], dev, first_stream=c["first"])
-            mo = run(pcm, min(args.verify, 8) if world == 1 else (2 if args.verify > 0 else 0), c=c, steps=4, warmup=2)
-            del pcm
-            torch.cuda.empty_cache()
-            others.append((c, mo))
+    for cfg in plan["other_configs"]:
+        c = config_setup(cfg)
+        pcm = synth_batch_gpu(torch, np, c["S"], c["F"], c["srs"], c["rhos"], c["wl"]["bursts"], dev, first_stream=c["first"])
+        mo = run(pcm, min(args.verify, 8) if world == 1 else (2 if args.verify > 0 else 0), c=c, steps=4, warmup=2)
+        # the same fed from page-locked host memory: the deployable rate of the configuration (PCIe both ways in the timed region)
+        mo["host_fed"] = run_host_fed(pcm, c=c, steps_h=4) if cfg in plan["host_fed_configs"] else None
+        del pcm
+        torch.cuda.empty_cache()
+        if dist is not None:        # streams verified: every rank's, summed
+            tv = torch.tensor([mo.get("verified", 0), mo.get("verify_n", 0), mo["status"] & 0x7FFFFFFF if mo["status"] >= 0 else 0x40000000],
+                              dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            lst = [torch.zeros_like(tv) for _ in range(world)]
+            dist.all_gather(lst, tv)
+            mo["verified_all"], mo["verify_n_all"] = int(sum(int(x[0]) for x in lst)), int(sum(int(x[1]) for x in lst))
+            mo["status_all"] = 0
+            for x in lst:
+                mo["status_all"] |= int(x[2])
+        others.append((c, mo))
+    # ---- strong scaling ("for transparency"): config 2's 1024 streams split over the ranks ----
+    strong = None
+    if plan["strong_scaling"]:
+        wl2 = workload(2)
+        f2, l2 = shard.shard_range(wl2["S"], world, rank)
+        cs = dict(cfg=2, wl=wl2, S=l2 - f2, F=wl2["F"], first=f2, ncls=1, kws=[wl2["classes"][0][0]] * (l2 - f2),
+                  srs=[wl2["classes"][0][1]] * (l2 - f2), rhos=[wl2["rho"][0]] * (l2 - f2))
+        pcm = synth_batch_gpu(torch, np, cs["S"], cs["F"], cs["srs"], cs["rhos"], False, dev, first_stream=f2)
+        ms_ = run(pcm, 2 if args.verify > 0 else 0, c=cs, steps=8, warmup=2)
+        del pcm
+        torch.cuda.empty_cache()
+        strong = (cs, ms_)
 
     # ---- every rank's health in the line: status word (OR), gate time-outs (sum), streams verified (sum) ----
     # status bit 0..2 are failures (hmp3_amd.h); a gate time-out costs overlap only and is counted separately
     mine_bad = (m["status"] != 0) or (m.get("verified", 0) != m.get("verify_n", 0)) or (host_fed is not None and host_fed["kernel_status"] != 0) \
         or (worst is not None and worst["status"] != 0) \
-        or any(mo["status"] != 0 or mo.get("verified", 0) != mo.get("verify_n", 0) for _, mo in others)
+        or any(mo["status"] != 0 or mo.get("verified", 0) != mo.get("verify_n", 0) or (mo.get("host_fed") is not None and mo["host_fed"]["kernel_status"] != 0) for _, mo in others) \
+        or (strong is not None and (strong[1]["status"] != 0 or strong[1].get("verified", 0) != strong[1].get("verify_n", 0)))
     if os.environ.get("HMP3AMD_BENCH_FAULT_RANK") == str(rank):      # test hook: this rank reports a failure (tests/test_gpu_runtime.py)
         mine_bad = True
     vals = [m["status"] & 0x7FFFFFFF if m["status"] >= 0 else 0x40000000, m["gate_timeouts"] or 0, m.get("verified", 0), m.get("verify_n", 0), 1 if mine_bad else 0, 1]
@@ -629,8 +663,15 @@ def main():
                            "kernel_build": (mo["k6"]["kernel"] if mo.get("k6") and mo["k6"]["kernel"] else "k_alloc"),
                            "resident_streams": mo["k6"]["resident_streams"] if mo.get("k6") else None,
                            "roofline_frac": round(ach_o / HBM_PEAK_GBS, 6) if ach_o else None,
-                           "verified_streams": mo.get("verified"), "verify_checked": mo.get("verify_n"), "kernel_status": mo["status"]})
+                           "verified_streams": mo.get("verified_all", mo.get("verified")), "verify_checked": mo.get("verify_n_all", mo.get("verify_n")),
+                           "kernel_status": mo.get("status_all", mo["status"]), "host_fed": mo.get("host_fed")})
             res["other_configs"] = oc
+        if strong is not None:
+            cs, ms_ = strong
+            res["strong_scaling"] = {"baseline_config": 2, "streams_total": workload(2)["S"], "streams_this_rank": cs["S"], "frames_per_step": cs["F"], "steps": 8, "warmup": 2,
+                                     "value": round(workload(2)["S"] * cs["F"] * 8 / ms_["dt"], 1), "unit": "frames/s", "ms_per_step": round(ms_["dt"] / 8 * 1e3, 3),
+                                     "kernel_ms_rank0": round(ms_["k_ms"], 3), "kernel_status_rank0": ms_["status"],
+                                     "what": "config 2's 1024 streams split over the %d ranks (total work fixed); the headline value is weak scaling (1024 streams per GPU)" % world}
         res["host_placement"] = placements      # per rank: device, its NUMA node, CPUs the rank was bound to, its own host-fed step time
         if not args.no_cpu_baseline:
             if cpus_before:

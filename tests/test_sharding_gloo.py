@@ -74,6 +74,27 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert rc == 0, err
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["streams_total"] == 2 * 1024
     assert line["max_time_token"] == 2.0            # max over ranks of (1 + rank)
+    # what an N-rank line carries beside `value`: the configs BASELINE defines on 8 GPUs, their host-fed rates, strong scaling
+    assert line["plan"] == {"other_configs": [4, 5], "host_fed_configs": [2, 4, 5], "strong_scaling": True, "worst_case": False}
+    assert line["strong_scaling_blocks"] == [[0, 512], [512, 1024]]
+
+
+def test_one_gpu_line_plans_every_other_config_with_its_host_fed_rate():
+    rc, line, err = _run_bench(["--dry-run"])
+    assert rc == 0, err
+    assert line["plan"] == {"other_configs": [3, 4, 5], "host_fed_configs": [2, 3, 4, 5], "strong_scaling": False, "worst_case": True}
+    rc, line, err = _run_bench(["--dry-run", "--config", "3"])
+    assert rc == 0 and line["plan"]["other_configs"] == [] and line["plan"]["host_fed_configs"] == []
+
+
+def test_eight_rank_config_2_line_plans_configs_4_and_5_and_the_strong_scaling_split():
+    """the first 8-GPU run of the driver (`bench.py --gpus 8`, config 2): weak-scaling headline, plus other_configs 4 and 5 (each
+    rank its 4096-stream share), their host-fed rates, and config 2's 1024 streams split eight ways"""
+    rc, line, err = _run_bench(["--gpus", "8", "--dry-run", "--backend", "gloo"], timeout=900)
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["streams_total"] == 8 * 1024
+    assert line["plan"] == {"other_configs": [4, 5], "host_fed_configs": [2, 4, 5], "strong_scaling": True, "worst_case": False}
+    assert line["strong_scaling_blocks"] == [[128 * r, 128 * (r + 1)] for r in range(8)]
 
 
 def test_bench_rejects_world_size_that_differs_from_gpus():
