@@ -143,13 +143,16 @@ struct hx_batch {
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
     bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
-    // longest-first workgroup order: 2 = always (default), 1 = only for batches beyond the resident set, 0 = never (HMP3AMD_LPT).
+    // longest-first workgroup order: 2 = for every batch with more streams than the chip has CUs (default: below that no two
+    // streams share a CU and the order decides nothing), 3 = always (tests), 1 = only for batches beyond the resident set,
+    // 0 = never (HMP3AMD_LPT).
     // Beyond the resident set it keeps the launch's last round short.  Within it the order decides which streams share a CU:
     // workgroups are dealt over XCDs and CUs in turn, so a CU's four streams are 256 apart in launch order - in stream order
     // those are streams of one residue class, and a batch whose slow streams recur with a period (BASELINE config 5: correlation
     // by stream mod 4) had them all on the same CUs; sorted by the previous call's duration a CU gets one stream of each quartile.
     // (Round 4: config 2 +1.0 %, its worst-case signal set +2.1 %.)
     int lpt = 2;
+    int ncu = 256;                      // compute units of the device
     int strict_sums = 0;                // HMP3AMD_EXACT_SUMS=1: the stream walk adds every band in line order instead of certifying a parallel sum (tests)
 };
 
@@ -295,6 +298,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         const size_t dyn = b->alloc1 ? (b->lsf ? K6_LDS(k_alloc1_lsf) : K6_LDS(k_alloc1)) : (b->lsf ? K6_LDS(k_alloc_lsf) : K6_LDS(k_alloc));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 128, dyn) != hipSuccess || per_cu <= 0) per_cu = 4;
         b->resident = per_cu * prop.multiProcessorCount;
+        b->ncu = prop.multiProcessorCount;
         // Two builds of the MPEG-1 stream walk.  A batch that the chip holds at once (config 2: 1024 streams on 256 CUs x 4)
         // runs the one written for 256 registers and 38 KB of LDS per stream; a larger one runs k_alloc_slim, whose streams
         // take 168 registers and 26.5 KB, six to a CU: a stream is slower there, 1.5 x as many are in flight.
@@ -302,6 +306,7 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         bool slim_ok = !b->alloc1 && !b->lsf;
         for (int k = 0; k < b->ncls && slim_ok; k++) slim_ok = hx_slim_tables_ok(&b->params[k], &gt) != 0;
         const char *e = getenv("HMP3AMD_K6");
+        if (e && strcmp(e, "slim") != 0 && strcmp(e, "fat") != 0) { set_err("HMP3AMD_K6 must be 'fat' or 'slim'"); hx_batch_destroy(b); return nullptr; }
         const bool want = e ? (strcmp(e, "slim") == 0) : (S > b->resident);
         if (e && strcmp(e, "slim") == 0 && !slim_ok && !b->alloc1 && !b->lsf) { set_err("HMP3AMD_K6=slim: the host's tables do not have the structure k_alloc_slim derives them from"); hx_batch_destroy(b); return nullptr; }
         if (want && slim_ok) {
@@ -632,7 +637,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.strict_sums = b->strict_sums;
     a.dur = b->d_dur;
     a.order = nullptr;
-    if ((S > b->resident && b->lpt) || b->lpt == 2) {       // longest first (see hx_batch::lpt)
+    if ((S > b->resident && b->lpt) || (b->lpt == 2 && S > b->ncu) || b->lpt == 3) {       // longest first (see hx_batch::lpt)
         LAUNCH(k_order, dim3(1), dim3(1024), qa, (const unsigned *) b->d_dur, b->d_order, S);
         a.order = b->d_order;
     }
@@ -1301,6 +1306,17 @@ extern "C" int hx_device_numa_node(int device)
     return node;
 }
 
+// The CPUs this process may use, captured once when the library is loaded (= before any thread was bound by it): a thread
+// that was bound to one device's node must be able to move to another device's node afterwards, so a node's CPU list is
+// intersected with this set, not with the calling thread's current mask.
+static cpu_set_t g_proc_cpus;
+static bool g_proc_cpus_ok = false;
+__attribute__((constructor)) static void capture_process_cpus()
+{
+    CPU_ZERO(&g_proc_cpus);
+    g_proc_cpus_ok = sched_getaffinity(0, sizeof(g_proc_cpus), &g_proc_cpus) == 0;
+}
+
 // the CPUs of a node that this process may use: parses /sys/devices/system/node/node<N>/cpulist ("0-15,128-143")
 static int node_cpus_allowed(int node, cpu_set_t *out)
 {
@@ -1310,10 +1326,7 @@ static int node_cpus_allowed(int node, cpu_set_t *out)
     if (!f) return 0;
     const bool got = fgets(buf, sizeof(buf), f) != nullptr;
     fclose(f);
-    if (!got) return 0;
-    cpu_set_t allowed;
-    CPU_ZERO(&allowed);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+    if (!got || !g_proc_cpus_ok) return 0;
     CPU_ZERO(out);
     int n = 0;
     for (char *p = buf; *p;) {
@@ -1321,17 +1334,16 @@ static int node_cpus_allowed(int node, cpu_set_t *out)
         long a = strtol(p, &e, 10), z = a;
         if (e == p) break;
         if (*e == '-') { p = e + 1; z = strtol(p, &e, 10); }
-        for (long c = a; c <= z && c < CPU_SETSIZE; c++) if (CPU_ISSET((int) c, &allowed)) { CPU_SET((int) c, out); n++; }
+        for (long c = a; c <= z && c < CPU_SETSIZE; c++) if (CPU_ISSET((int) c, &g_proc_cpus)) { CPU_SET((int) c, out); n++; }
         p = (*e == ',') ? e + 1 : e;
         if (*e != ',') break;
     }
     return n;
 }
 
-// bind the calling thread to the allowed CPUs of `device`'s NUMA node; returns how many CPUs that is (0: left as it was)
-extern "C" int hx_bind_thread_to_device(int device)
+// bind the calling thread to the allowed CPUs of NUMA node `node`; returns how many CPUs that is (0: left as it was)
+extern "C" int hx_bind_thread_to_node(int node)
 {
-    const int node = hx_device_numa_node(device);
     if (node < 0) return 0;
     cpu_set_t set;
     const int n = node_cpus_allowed(node, &set);
@@ -1339,9 +1351,17 @@ extern "C" int hx_bind_thread_to_device(int device)
     return sched_setaffinity(0, sizeof(set), &set) == 0 ? n : 0;
 }
 
+// bind the calling thread to the allowed CPUs of `device`'s NUMA node; returns how many CPUs that is (0: left as it was)
+extern "C" int hx_bind_thread_to_device(int device)
+{
+    return hx_bind_thread_to_node(hx_device_numa_node(device));
+}
+
 struct hx_multi {
     std::vector<hx_batch *> part;
     std::vector<int> first, count, device;
+    std::vector<cpu_set_t> cpus;        // per device: the CPUs of its NUMA node this process may use (resolved once, at creation)
+    std::vector<int> ncpus;             // ... and how many (0: unknown, the device's thread stays where it is)
     int S = 0, nchan = 2;
 };
 
@@ -1368,6 +1388,11 @@ extern "C" hx_multi *hx_multi_create(int ndev, const int *devices, int nstreams,
         hx_batch *b = hx_batch_create(dev, count, shared_control ? ec : ec + first, shared_control, max_frames);
         if (!b) { hx_multi_destroy(m); return nullptr; }            // hx_last_error is hx_batch_create's
         m->part.push_back(b); m->first.push_back(first); m->count.push_back(count); m->device.push_back(dev);
+        cpu_set_t cs;
+        CPU_ZERO(&cs);
+        const int node = hx_device_numa_node(dev);
+        m->ncpus.push_back(node >= 0 ? node_cpus_allowed(node, &cs) : 0);
+        m->cpus.push_back(cs);
         if (k == 0) m->nchan = b->nchan;
         else if (b->nchan != m->nchan || b->lsf != m->part[0]->lsf) { set_err("mono / stereo and MPEG-1 / MPEG-2 streams cannot share a batch"); hx_multi_destroy(m); return nullptr; }
     }
@@ -1404,7 +1429,7 @@ static int multi_call(hx_multi *m, int kind, const void *pcm, int nframes, unsig
     std::vector<std::thread> th;
     for (size_t k = 0; k < n; k++)
         th.emplace_back([&, k]() {
-            hx_bind_thread_to_device(m->device[k]);     // this device's copies are issued from its own socket (best effort)
+            if (m->ncpus[k] > 0) sched_setaffinity(0, sizeof(cpu_set_t), &m->cpus[k]);     // this device's copies are issued from its own socket (best effort)
             const long long f = m->first[k];
             const char *p = (const char *) pcm + (size_t) f * nframes * 1152 * m->nchan * esz;
             unsigned char *o = out + f * out_stride;

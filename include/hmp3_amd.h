@@ -199,9 +199,12 @@ float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls);
    buffers and the threads that submit its copies belong on the NUMA node the device hangs on.
    hx_device_numa_node: that node from sysfs (-1 = unknown or not a NUMA machine).  hx_bind_thread_to_device: restricts the
    calling thread to the CPUs of that node which the process may use and returns their number (0 = nothing changed); call it
-   before hx_pinned_alloc so that first touch places the pages there.  hx_multi_* binds its per-device threads itself. */
+   before hx_pinned_alloc so that first touch places the pages there.  hx_multi_* binds its per-device threads itself.
+   "The CPUs the process may use" are the ones its loading thread had when the library was loaded: a thread bound to one
+   device's node can be bound to another device's node afterwards.  hx_bind_thread_to_node: the same by node number. */
 int hx_device_numa_node(int device);
 int hx_bind_thread_to_device(int device);
+int hx_bind_thread_to_node(int node);
 
 /* ---- several GPUs of one node behind one handle (no reference equivalent) ----
    nstreams independent streams in contiguous blocks over ndev devices (devices[0..ndev), or devices

@@ -153,14 +153,15 @@ def test_cli_streams_from_a_pipe_with_bounded_buffers(name, tmp_path):
 
 
 @pytest.mark.gpu
-def test_longest_first_workgroup_order_changes_nothing_in_the_output(monkeypatch):
-    """Batches beyond what the chip holds at once start their allocator workgroups by the previous call's stream durations,
-    longest first (hx_cabi.hip k_order); forced here on a small batch (HMP3AMD_LPT=2), three calls so that the order is a
-    real permutation, against the oracle"""
+@pytest.mark.parametrize("lpt", ["3", "0"])
+def test_longest_first_workgroup_order_changes_nothing_in_the_output(monkeypatch, lpt):
+    """Batches with more streams than the chip has CUs start their allocator workgroups by the previous call's stream
+    durations, longest first (hx_cabi.hip k_order); forced here on a small batch (HMP3AMD_LPT=3), three calls so that the
+    order is a real permutation, against the oracle - and the identity order (HMP3AMD_LPT=0) the same"""
     import numpy as np
     from hmp3_amd import api, synth
     from oracle import oracle as O
-    monkeypatch.setenv("HMP3AMD_LPT", "2")
+    monkeypatch.setenv("HMP3AMD_LPT", lpt)
     S, F, calls = 24, 12, 3
     rhos = [0.7, 0.0, 1.0, 0.3]
     pcm = np.stack([synth.stream_pcm(7700 + i, F * calls, rho=rhos[i % 4], bursts=(i % 3 == 0)) for i in range(S)])
@@ -440,3 +441,11 @@ def test_host_placement_helpers_are_best_effort_and_harmless(k6_build):
         b.close()
     finally:
         os.sched_setaffinity(0, before)
+
+
+@pytest.mark.gpu
+def test_k6_build_switch_takes_only_its_two_values(monkeypatch):
+    from hmp3_amd import api
+    monkeypatch.setenv("HMP3AMD_K6", "Slim")
+    with pytest.raises(Exception):
+        api.Batch(api.default_control(bitrate=64), nstreams=2, max_frames=2)

@@ -150,3 +150,29 @@ def test_host_tables_have_the_structure_the_low_footprint_kernel_derives_them_fr
     assert pexp[0] == 0 and np.isinf(pexp[255])
     mblog = tab("mblog", 256, np.int32)
     assert mblog.min() + 38227 >= 0 and mblog.max() + 38227 <= 301
+
+
+def test_a_thread_bound_to_one_node_can_be_bound_to_another():
+    """hx_bind_thread_to_node / _device intersect a node's CPU list with the CPUs the PROCESS may use (captured when the library
+    was loaded), not with the calling thread's current mask: a thread that was narrowed before - here to one CPU, as if bound to
+    another device's node - is widened to the whole node again (round 4's advisor finding: the second bind did nothing)."""
+    from hmp3_amd import api
+    if not hasattr(os, "sched_getaffinity") or not os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        pytest.skip("no sysfs NUMA description on this host")
+    api.lib()                                   # library loaded: the process mask is captured now
+    before = os.sched_getaffinity(0)
+    spec = open("/sys/devices/system/node/node0/cpulist").read().strip()
+    node0 = set()
+    for part in spec.split(","):
+        a, _, z = part.partition("-")
+        node0 |= set(range(int(a), int(z or a) + 1))
+    want = node0 & before
+    if len(want) < 2:
+        pytest.skip("fewer than two usable CPUs on node 0")
+    try:
+        os.sched_setaffinity(0, {min(want)})
+        n = api.bind_thread_to_node(0)
+        assert n == len(want) and os.sched_getaffinity(0) == want
+        assert api.bind_thread_to_node(-1) == 0 and os.sched_getaffinity(0) == want      # unknown node: left as it was
+    finally:
+        os.sched_setaffinity(0, before)
