@@ -27,10 +27,18 @@ UNITS = [   # (name, source, flags) as hmp3_amd/build.sh compiles them
     ("alloc1", "hx_alloc1.hip", ["-O2"] + ILP + NOLICM),
     ("alloc1_lsf", "hx_alloc1_lsf.hip", ["-O2"] + ILP + NOLICM),
 ]
-# Functions of the stream walk whose FLAT instructions address global or private memory (checked by reading them): the
-# double-precision x^(4/3) table, the psy model's outputs of the front end, packet outputs, a by-reference result on the stack.
-ALLOWED = ("sweep_lines_big", "lucky_terms_big", "bitallo_short", "compute_mask_short", "hf_adjust_ch", "pack_side", "pack_side_lsf", "emit_packet",
-           "pow43_beyond", "a1_", "bitallo1", "dblog", "pack_sf_lsf")
+# Functions of the stream walk whose FLAT instructions address global or private memory (checked by reading them: the
+# double-precision x^(4/3) table and the double-table counter, the psy model's outputs of the front end, packet outputs, a
+# by-reference result on the stack), with the number of FLAT instructions each has today: one more in any of them fails the
+# check and has to be read before the number is raised.  (A name is matched as a prefix of the demangled function name.)
+ALLOWED = {"sweep_run_stored": 3, "void lucky_terms_big<2>": 2, "void lucky_terms_big<3>": 3, "compute_mask_short": 5, "hf_adjust_ch": 1,
+           "bitallo_short": 2, "pack_side": 1, "pack_side_lsf": 1, "emit_packet": 2, "bitallo1": 22, "pack_sf_lsf": 2, "pack_sf_lsf_is": 2,
+           "pow43_beyond": 0, "dblog": 0}
+
+
+def allowed(dem, n):
+    name = dem.split("(")[0]
+    return name in ALLOWED and n <= ALLOWED[name]
 
 
 def flat_ops(path):
@@ -47,6 +55,10 @@ def flat_ops(path):
 
 
 def main():
+    if "--print-flags" in sys.argv:      # the flags this check compiles with, unit by unit (tests compare them with hmp3_amd/build.sh)
+        for name, src, flags in UNITS:
+            print(name, src, " ".join(flags))
+        return
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     tmp = keep or tempfile.mkdtemp(prefix="hxflat.")
     os.makedirs(tmp, exist_ok=True)
@@ -63,7 +75,7 @@ def main():
         ops = flat_ops(out)
         names = subprocess.run(["c++filt"], input="\n".join(ops), capture_output=True, text=True).stdout.split("\n")
         for mangled, dem in zip(ops, names):
-            if name.startswith("alloc") and any(a in dem for a in ALLOWED):
+            if name.startswith("alloc") and allowed(dem, ops[mangled]):
                 continue
             bad.append("%s: %s has %d FLAT instruction(s)" % (name, dem, ops[mangled]))
     if bad:
