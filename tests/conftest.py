@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "one_k6_build: a GPU test whose batches never reach the k_alloc / k_alloc_slim switch (or that is long and about something else): run once, not once per build")
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -33,13 +34,14 @@ def has_gpu():
 # low-footprint build, six per CU), forced through the library's environment switch; the bytes must not differ.
 # (MPEG-2 and first-generation-allocator batches have one kernel each and ignore the switch.)
 # tests whose batches never reach the switch (MPEG-2 rates and first-generation-allocator streams have one kernel each; the
-# whole-file sweep against the reference's binary and the two-device tests are long and about something else): once
+# whole-file sweep against the reference's binary and the two-device tests are long and about something else): once.
+# New tests say so with @pytest.mark.one_k6_build; the name fragments below cover the ones that predate the marker.
 ONE_BUILD = ("mpeg2", "lsf", "intensity", "negative_scalefactors", "fuzz_cli", "two_physical", "extra_golden", "src_convert")
 
 
 def pytest_generate_tests(metafunc):
     if metafunc.definition.get_closest_marker("gpu") is not None and "k6_build" in metafunc.fixturenames:
-        once = any(p in metafunc.function.__name__ for p in ONE_BUILD)
+        once = metafunc.definition.get_closest_marker("one_k6_build") is not None or any(p in metafunc.function.__name__ for p in ONE_BUILD)
         metafunc.parametrize("k6_build", ["fat"] if once else ["fat", "slim"], indirect=True)
 
 

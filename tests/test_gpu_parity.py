@@ -767,6 +767,33 @@ def test_full_batch_configs_3_and_5(cfg):
     b.close()
 
 
+def test_config_4_share_at_full_length():
+    """One GPU's share of BASELINE config 4 at its full size - 4096 streams x 128 frames, 48 kHz, VBR -V100 -HF2 -F19000 - in
+    one call (the 4096-stream configs otherwise run at 32 frames here and at full length only in bench.py's verify): 64
+    distinct signals rotated in time, a 16-stream oracle subset byte for byte, frame structure of every 97th stream"""
+    a = api()
+    S, F, U = 4096, 128, 64
+    kw, sr = dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), 48000
+    base = [synth.stream_pcm(9900 + u, F, sr=sr, rho=RHOS[u % 4], bursts=True) for u in range(U)]
+    pcm = np.stack([np.roll(base[i % U], 1152 * 2 * (i // U), axis=0) for i in range(S)])
+    b = a.Batch(a.default_control(**kw), nstreams=S, max_frames=F)
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    assert b.k6_variant() == (1 if os.environ.get("HMP3AMD_K6", "slim") == "slim" else 0)      # beyond the resident set: the low-footprint build unless forced
+    rng = np.random.Generator(np.random.PCG64(12))
+    for s in rng.choice(S, 16, replace=False):
+        assert got[s] == oracle_bytes(kw, pcm[s], F), "stream %d" % s
+    for s in range(0, S, 97):
+        bs, pos, n = got[s], 0, 0
+        while pos < len(bs):
+            assert bs[pos] == 0xFF and (bs[pos + 1] & 0xFE) == 0xFA
+            br = [0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320][bs[pos + 2] >> 4]
+            pos += 144000 * br // sr + ((bs[pos + 2] >> 1) & 1)
+            n += 1
+        assert pos == len(bs) and F - 6 <= n <= F
+    b.close()
+
+
 def test_ragged_calls_equal_one_shot():
     """state carry across calls: 1 + 7 + 24 frames in three calls == 32 frames in one call"""
     kw = CONFIGS["vbr50_sw"]       # block switching on: the carry includes detector and block-type state
