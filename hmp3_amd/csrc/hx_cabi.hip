@@ -1031,10 +1031,10 @@ extern "C" long long hx_debug_host_table(const HX_E_CONTROL *ec, const char *nam
     TAB("anwin", g.anwin) TAB("mblog", g.mblog) TAB("mbexp_lo", g.mbexp_lo) TAB("mbexp_hi", g.mbexp_hi)
     TAB("pow34_exp", g.pow34_exp) TAB("quant_off", g.quant_off) TAB("logsub", g.logsub)
     TAB("huff_code", g.huff_code) TAB("huff_len", g.huff_len)
-    TAB("lane_run", p.lane_run) TAB("band_last_lane", p.band_last_lane) TAB("lucky_run", p.lucky_run) TAB("lucky_last", p.lucky_last)
+    TAB("lane_run", p.lane_run) TAB("band_last_lane", p.band_last_lane)
     TAB("nchan", p.nchan)
 #undef TAB
-    if (k == "run_w") { static int v[2]; v[0] = p.run_w; v[1] = p.lucky_w; src = v; n = sizeof(v); }
+    if (k == "run_w") { static int v[1]; v[0] = p.run_w; src = v; n = sizeof(v); }
     if (k == "scalars") {
         static int v[16];
         v[0] = p.nsb_limit; v[1] = p.nsb_ms0; v[2] = p.band_limit; v[3] = p.main_framebytes; v[4] = p.AveTargetBits;

@@ -374,11 +374,11 @@ static void alloc1_tables(HxParams *p)
     memcpy(p->a1_sparse, p->h_id ? sp1 : sp2, sizeof(p->a1_sparse));
 }
 
-// Blocked line runs for the stream walk's certified band sums (hx_alloc.hip: noise_sweep, inverse_sf2, big_lucky_noise).
+// Blocked line runs for the stream walk's certified band sums (hx_alloc.hip: noise_sweep, inverse_sf2).
 // The bands 0 .. nb-1 are cut into runs of at most W consecutive lines, one run per lane, a band's runs in neighbouring
 // lanes; W = the smallest even width with which the runs fit the 64 lanes and no band takes more than maxl <= 16 of them (the
 // segmented scan over a band's lanes crosses at most one 16-lane row boundary).  Returns W, 0 if there is none in wmin .. wmax.
-static int cut_runs(const int *width, const int *first, int nb, int wmin, int wmax, int maxl, int lane0, int nlanes, unsigned short *run, unsigned char *last, int chbit)
+static int cut_runs(const int *width, const int *first, int nb, int wmin, int wmax, int maxl, int lane0, int nlanes, unsigned short *run, unsigned char *last)
 {
     for (int W = wmin; W <= wmax; W += 2) {
         int lanes = 0, ok = 1;
@@ -389,7 +389,7 @@ static int cut_runs(const int *width, const int *first, int nb, int wmin, int wm
             const int c = (width[b] + W - 1) / W;
             for (int k = 0; k < c; k++, l++) {
                 const int st = first[b] + k * W, n = MN(W, width[b] - k * W);
-                run[l] = (unsigned short) ((st >> 1) | ((n >> 1) << 9) | (k << 12) | chbit);
+                run[l] = (unsigned short) ((st >> 1) | ((n >> 1) << 9) | (k << 12));
             }
             last[b] = (unsigned char) (l - 1);
         }
@@ -401,28 +401,12 @@ static int cut_runs(const int *width, const int *first, int nb, int wmin, int wm
 static int band_runs(HxParams *p)
 {
     memset(p->lane_run, 0, sizeof(p->lane_run));
-    memset(p->lucky_run, 0, sizeof(p->lucky_run));
     memset(p->band_last_lane, 0, sizeof(p->band_last_lane));
-    memset(p->lucky_last, 0, sizeof(p->lucky_last));
     // (every long band starts on an even line and has an even width: ISO Table B.8; the packed form relies on it)
     for (int b = 0; b < 22; b++) if ((p->startBand_l[b] | p->nBand_l[b]) & 1) return 0;
     const int nb = MX(p->nsf[0], p->nchan == 2 ? p->nsf[1] : 0);
-    p->run_w = cut_runs(p->nBand_l, p->startBand_l, nb, 2, 10, 16, 0, 64, p->lane_run, p->band_last_lane, 0);
+    p->run_w = cut_runs(p->nBand_l, p->startBand_l, nb, 2, 10, 16, 0, 64, p->lane_run, p->band_last_lane);
     if (nb > 0 && !p->run_w) return 0;
-    // big_lucky_noise measures bands 0..12 of both channels in one pass: channel 0's runs, then channel 1's (at most 8 lanes per
-    // band: the packed form has three bits for a lane's distance to its band's first one)
-    const int m0 = MN(13, p->nsf[0]), m1 = p->nchan == 2 ? MN(13, p->nsf[1]) : 0;
-    for (int W = 2; W <= 6; W += 2) {
-        int n0 = 0, n1 = 0;
-        for (int b = 0; b < m0; b++) n0 += (p->nBand_l[b] + W - 1) / W;
-        for (int b = 0; b < m1; b++) n1 += (p->nBand_l[b] + W - 1) / W;
-        if (n0 + n1 > 64) continue;
-        if (!cut_runs(p->nBand_l, p->startBand_l, m0, W, W, 8, 0, 64, p->lucky_run, p->lucky_last[0], 0)) continue;
-        if (!cut_runs(p->nBand_l, p->startBand_l, m1, W, W, 8, n0, 64 - n0, p->lucky_run, p->lucky_last[1], 1 << 15)) continue;
-        p->lucky_w = W;
-        break;
-    }
-    if ((m0 + m1) > 0 && !p->lucky_w) return 0;
     return 1;
 }
 

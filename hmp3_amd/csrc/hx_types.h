@@ -52,11 +52,10 @@ struct HxParams {
     // Blocked line runs of the stream walk's certified band sums (hx_alloc.hip, noise_sweep / inverse_sf2; hx_host.cpp band_runs):
     // lane l owns up to run_w consecutive lines of ONE band among the bands the gain search measures, the lanes of a band are
     // neighbours (at most 16).  lane_run[l] = first line >> 1 | (lines >> 1) << 9 | (lanes between l and its band's first lane) << 12;
-    // band_last_lane[b] = the last lane of band b's run of lanes.  The same for big_lucky_noise's bands 0..12 of both channels
-    // (lucky_w, lucky_run: channel << 15 | lanes to the band's first << 12 | (lines >> 1) << 9 | first line >> 1; lucky_last[ch][b]).
-    int run_w, lucky_w;
-    unsigned short lane_run[64], lucky_run[64];
-    unsigned char band_last_lane[24], lucky_last[2][16];
+    // band_last_lane[b] = the last lane of band b's run of lanes.
+    int run_w;
+    unsigned short lane_run[64];
+    unsigned char band_last_lane[24];
     // 32-point analysis DCT: twiddles 2 cos(pi (2j+1) / 2N) of the size-N step at [N/2 + j] (heap order; [0] unused)
     float dct_tw[32];
     float win[4][36], csa[2][8];

@@ -38,7 +38,7 @@ RUN_CONFIGS = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_fl
 @pytest.mark.skipif(not os.path.exists(LIB), reason="hmp3_amd/libhmp3amd.so not built (hmp3_amd/build.sh)")
 @pytest.mark.parametrize("kw", RUN_CONFIGS, ids=[str(i) for i in range(len(RUN_CONFIGS))])
 def test_line_runs_tile_the_measured_bands(kw):
-    """HxParams::lane_run / lucky_run: every line of every band the gain search (big_lucky_noise) measures belongs to exactly one
+    """HxParams::lane_run: every line of every band the gain search measures belongs to exactly one
     lane's run, a run stays inside one band, a band's lanes are neighbours (at most 16: the segmented scan crosses one row
     boundary at most), and the 'lanes back to the band's first lane' field counts them"""
     from hmp3_amd import api
@@ -51,7 +51,7 @@ def test_line_runs_tile_the_measured_bands(kw):
         return a
     start, width, nsf = tab("startBand_l", np.int32, 24), tab("nBand_l", np.int32, 22), tab("nsf", np.int32, 2)
     nchan = int(tab("nchan", np.int32, 1)[0])
-    W, LW = [int(v) for v in tab("run_w", np.int32, 2)]
+    W = int(tab("run_w", np.int32, 1)[0])
     run, last = tab("lane_run", np.uint16, 64), tab("band_last_lane", np.uint8, 24)
     nb = max(int(nsf[0]), int(nsf[1]) if nchan == 2 else 0)
     assert 2 <= W <= 10 and W % 2 == 0
@@ -88,7 +88,3 @@ def test_line_runs_tile_the_measured_bands(kw):
             assert int(run[l]) == 0
 
     check(run, [last], [(0, b) for b in range(nb)], W, 0)
-    lrun, llast = tab("lucky_run", np.uint16, 64), tab("lucky_last", np.uint8, 32).reshape(2, 16)
-    bands = [(0, b) for b in range(min(13, int(nsf[0])))] + ([(1, b) for b in range(min(13, int(nsf[1])))] if nchan == 2 else [])
-    assert 2 <= LW <= 6
-    check(lrun, llast, bands, LW, 1)
