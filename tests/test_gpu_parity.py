@@ -127,6 +127,32 @@ def test_loud_near_mono_material_takes_the_double_table_path(kw):
     b.close()
 
 
+@pytest.mark.parametrize("kw", [dict(bitrate=64, short_block_threshold=99999), dict(vbr_mnr=50), dict(bitrate=80, hf_flag=3, freq_limit=19000), dict(bitrate=64, samprate=32000),
+                                dict(bitrate=32, samprate=22050)],
+                         ids=["cbr128_long", "vbr50", "cbr160_hf", "cbr128_32k", "lsf_cbr64"])
+def test_certified_band_sums_and_strict_band_sums_give_the_same_bytes(kw, monkeypatch):
+    """The stream walk proves the mbLogC bucket of a band's noise from a parallel sum and an error interval, and adds the band's
+    terms in the reference's line order only when the interval straddles a bucket boundary (hx_dev.h, "certified band sums").
+    Both ways equal the oracle: with the real interval (a small share of the sums fall back: the device counter says how many)
+    and with HMP3AMD_EXACT_SUMS=1, which sends every sum down the strict path.  rho cycled, so the double-table path is in."""
+    sr = kw.get("samprate", 44100)
+    S, F = 8, 40
+    pcm = np.stack([synth.stream_pcm(8300 + i, F, sr=sr, rho=RHOS[i % 4], bursts=wants_bursts(kw)) for i in range(S)])
+    want = [oracle_bytes(kw, pcm[s], F) for s in range(S)]
+    counts = []
+    for strict in ("0", "1"):
+        monkeypatch.setenv("HMP3AMD_EXACT_SUMS", strict)
+        b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+        got = b.encode_host(pcm)
+        assert b.status() == 0
+        for s in range(S):
+            assert got[s] == want[s], ("strict sums" if strict == "1" else "certified sums", "stream %d" % s)
+        counts.append(int(b.debug_read("strict_sums", np.int32, 1)[0]))
+        b.close()
+    # a few per cent of the gain-search sweeps have a band that needs the strict sum; forced, every sweep and every inverse_sf2 does
+    assert counts[1] > 20 * max(counts[0], 1) and counts[1] > 4 * S * F, counts
+
+
 NEG_SF_CASES = [   # found by tools/fuzz_parity.py: quiet dual-channel VBR material
     (dict(samprate=48000, mode=2, vbr_mnr=131), 109814, 0.0, 12, False),
     (dict(samprate=48000, mode=2, vbr_mnr=36, hf_flag=3, short_block_threshold=2000, filter_select=1), 370635, 0.7, 12, True),
