@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "gpu_long: long randomised sweeps on a real MI355X (python -m pytest tests -m gpu_long; not part of -m gpu, which has to fit the driver's window)")
     config.addinivalue_line("markers", "one_k6_build: a GPU test whose batches never reach the k_alloc / k_alloc_slim switch (or that is long and about something else): run once, not once per build")
 
 
