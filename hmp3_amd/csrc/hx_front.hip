@@ -541,7 +541,7 @@ __device__ __forceinline__ void psy_long2(const float *xl, const HxParams *p, co
 // M/S decision metric before hysteresis: lane = scalefactor band (reference bitallo3.cpp:695-742);
 // x0 / x1 = the two channels' lines (LDS)
 __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, const HxParams *p, const int *t_mblog,
-                                              int *out, bool is_short, int sb_start, int sb_n)
+                                              int *out, bool is_short, int sb_start, int sb_n, unsigned run_word, int band_last)
 {
     const int lane = threadIdx.x & 63;
     int v = 0;
@@ -582,10 +582,61 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
         if (lane == 0) *out = p->nsf[0] - 3 * d;
         return;
     }
-    if (lane < p->nsf[0]) {
-        int k = sb_start, n = sb_n;
+    // The band's three sums - el = 100 + sum l^2, er = 100 + sum r^2 and the signed t = sum l r, each in line order in the
+    // reference - feed four mbLogC arguments only: el + er, max(el, er), es + ed and max(es, ed) (es, ed = (el + er) +- 2 t).
+    // So the lanes add the terms of their line runs (the runs of the stream walk's certified band sums, HxParams::lane_run),
+    // a segmented scan brings the band's totals to its last lane, and the band lane certifies the four buckets from the
+    // intervals the strict sums must lie in (hx_dev.h; the signed sum's half-width comes from sum |l r|); it runs the strict
+    // loop only when an interval straddles a bucket boundary (about one band in a hundred).  Before, a wave paid for the widest
+    // band's 76 iterations with a third of its lanes in the loop: a third of this kernel's instructions.
+    // (tests/cert_sums_check.c checks the certificates on correlated channel pairs of every kind.)
+    const bool bandlane = lane < p->nsf[0];
+    bool strict = bandlane;
+    int mblr = 0, mbsd = 0;
+    if (p->ms_flag) {
+        const int W = p->run_w;
+        const int start = (int) (run_word & 511u) << 1, cnt = (int) ((run_word >> 9) & 7u) << 1, d = (int) (run_word >> 12);
+        float sa = 0.0f, sb = 0.0f, sc = 0.0f, sm = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 10; k += 2) {
+            if (k < W) {
+                const float2 l = *reinterpret_cast<const float2 *>(x0 + start + k), r = *reinterpret_cast<const float2 *>(x1 + start + k);
+                const bool in = k < cnt;
+                const float a0 = in ? l.x * l.x : 0.0f, a1 = in ? l.y * l.y : 0.0f, b0 = in ? r.x * r.x : 0.0f, b1 = in ? r.y * r.y : 0.0f;
+                const float c0 = in ? l.x * r.x : 0.0f, c1 = in ? l.y * r.y : 0.0f;
+                sa += (a0 + a1); sb += (b0 + b1); sc += (c0 + c1); sm += (fabsf(c0) + fabsf(c1));
+            }
+        }
+        const int last4 = 4 * band_last;
+        const float SA = hx_lane_read(last4, hx_seg_scan(sa, d, lane)), SB = hx_lane_read(last4, hx_seg_scan(sb, d, lane));
+        const float SC = hx_lane_read(last4, hx_seg_scan(sc, d, lane)), SM = hx_lane_read(last4, hx_seg_scan(sm, d, lane));
+        if (bandlane) {
+            const float du = hx_cert_delta(sb_n + 1, W);      // (the 100 in front is one more term and one more addition)
+            const float tel = 100.0f + SA, ter = 100.0f + SB;
+            const float e1 = tel * du, e2 = ter * du, e3 = SM * du;
+            // (a sum of non-negative terms that starts at 100 never falls below 100: rounding is monotone)
+            const float el_lo = fmaxf(tel - e1, 100.0f), el_hi = tel + e1, er_lo = fmaxf(ter - e2, 100.0f), er_hi = ter + e2;
+            const float t_lo = SC - e3, t_hi = SC + e3;
+            const float tl2 = t_lo + t_lo, th2 = t_hi + t_hi;
+            const float p1_lo = el_lo + er_lo, p1_hi = el_hi + er_hi;
+            const float p2_lo = fmaxf(el_lo, er_lo), p2_hi = fmaxf(el_hi, er_hi);
+            const float es_lo = p1_lo + tl2, es_hi = p1_hi + th2, ed_lo = p1_lo - th2, ed_hi = p1_hi - tl2;
+            const float p3_lo = es_lo + ed_lo, p3_hi = es_hi + ed_hi;
+            // (one of es, ed is el + er plus something non-negative, rounded: max(es, ed) >= el + er)
+            const float p4_lo = fmaxf(fmaxf(es_lo, ed_lo), p1_lo), p4_hi = fmaxf(es_hi, ed_hi);
+            const bool ok = p3_lo > 0.0f && p4_lo > 0.0f && (hx_f2bits(p1_lo) >> 15) == (hx_f2bits(p1_hi) >> 15) && (hx_f2bits(p2_lo) >> 15) == (hx_f2bits(p2_hi) >> 15)
+                            && (hx_f2bits(p3_lo) >> 15) == (hx_f2bits(p3_hi) >> 15) && (hx_f2bits(p4_lo) >> 15) == (hx_f2bits(p4_hi) >> 15);
+            if (ok) {       // every point of a certified interval has the strict value's log: take the lower ends
+                strict = false;
+                mblr = hx_mblog(t_mblog, p1_lo) - hx_mblog(t_mblog, p2_lo);
+                mbsd = hx_mblog(t_mblog, p3_lo) - hx_mblog(t_mblog, p4_lo);
+            }
+        }
+    }
+    if (strict) {
+        int k = sb_start;
         float el = 100.0f, er = 100.0f, t = 0.0f;
-        for (int j = 0; j < n; j++, k++) {
+        for (int j = 0; j < sb_n; j++, k++) {
             float a = x0[k] * x0[k], b = x1[k] * x1[k], c = x0[k] * x1[k];
             el += a; er += b; t += c;
         }
@@ -594,12 +645,14 @@ __device__ __forceinline__ void msmetric_unit(const float *x0, const float *x1, 
         t = t + t;
         es = es + t;
         ed = ed - t;
-        int mblr = hx_mblog(t_mblog, el + er) - hx_mblog(t_mblog, el > er ? el : er);
-        int mbsd = hx_mblog(t_mblog, es + ed) - hx_mblog(t_mblog, es > ed ? es : ed);
+        mblr = hx_mblog(t_mblog, el + er) - hx_mblog(t_mblog, el > er ? el : er);
+        mbsd = hx_mblog(t_mblog, es + ed) - hx_mblog(t_mblog, es > ed ? es : ed);
+    }
+    if (bandlane) {
         int psd = max(75 - abs(mblr - 120), 0);
         mbsd = min(mbsd, (mbsd >> 1) + 120);
         mbsd += psd;
-        v = n * (mblr - mbsd);
+        v = sb_n * (mblr - mbsd);
     }
     v = hx_wave_sum(v);
     if (lane == 0) *out = v;
@@ -643,6 +696,8 @@ __device__ __forceinline__ void spec_granule(const float *__restrict__ sb, const
     pc.i0 = p->psyL.pstart[lane]; pc.nsum = p->psyL.nsum[lane]; pc.off = p->psyL.off[lane]; pc.cnt = p->psyL.cnt[lane];
     pc.row = p->psyL.row[lane]; pc.wabs = p->psyL.w[lane];
     const int sb_start = p->startBand_l[min(lane, 22)], sb_n = p->nBand_l[min(lane, 21)];
+    const unsigned run_word = p->lane_run[lane];            // the lane's line run and its band's last lane, for the stereo metric's sums
+    const int band_last = p->band_last_lane[min(lane, 21)];
     __syncthreads();        // the tables (the only workgroup barrier: from here on each wave is on its own)
     const int nsb = p->nsb_ms0;
     const int btype = bt[sg];
@@ -755,7 +810,7 @@ __device__ __forceinline__ void spec_granule(const float *__restrict__ sb, const
         psy_short(xs, pg, (HX_GLB float *) (etab_out + sg * 128), (HX_GLB float *) (thr_out + sg * 128), ess);
         psy_short(xs + 576, pg, (HX_GLB float *) (etab_out + sg * 128 + 64), (HX_GLB float *) (thr_out + sg * 128 + 64), ess);
     }
-    msmetric_unit(xl, xl + 576, p, T.mblog, msbase + sg, btype == 2, sb_start, sb_n);
+    msmetric_unit(xl, xl + 576, p, T.mblog, msbase + sg, btype == 2, sb_start, sb_n, run_word, band_last);
 }
 
 #define HX_K4(name, direct) \

@@ -1,10 +1,11 @@
 /* cert_sums_check.c - CPU property test of the stream walk's certified band sums (hmp3_amd/csrc/hx_dev.h, "certified band
- * sums"; hx_alloc.hip noise_sweep / inverse_sf2 / big_lucky_noise).  Test infrastructure: restates, in plain C and fp32, the
+ * sums"; hx_alloc.hip noise_sweep / inverse_sf2; hx_front.hip msmetric_unit).  Test infrastructure: restates, in plain C and fp32, the
  * reduction the kernels run - a lane adds its run of at most W terms (both tree shapes the kernels use), a segmented
  * Hillis-Steele scan over the band's lanes (row_shr 1/2/4/8 inside 16-lane rows, row_bcast:15 / row_bcast:31 across a row
  * boundary) - and checks, for random and adversarial vectors of non-negative terms, that the reference's strict left-to-right
  * fp32 sum (l3math.c:521-537) lies inside the interval the kernels certify with, and that a certified bucket is the strict
- * sum's bucket of mbLogC (l3math.c:228-242: exponent and top 8 mantissa bits).  The same for the quotient of two sums.
+ * sum's bucket of mbLogC (l3math.c:228-242: exponent and top 8 mantissa bits).  The same for the quotient of two sums and for
+ * the stereo metric's sums (hx_front.hip msmetric_unit).
  *
  *   cert_sums_check <vectors> <seed>      exit 0 = every vector inside its interval; prints the straddle rate
  * Build: gcc -O2 -ffp-contract=off -o cert_sums_check cert_sums_check.c -lm
@@ -105,11 +106,61 @@ static float rand_term(int family, int i, int n, float scale)
     }
 }
 
+/* ---- the stereo metric's band sums (hx_front.hip msmetric_unit; reference bitallo3.cpp:695-742): el = 100 + sum l^2, er = 100 + sum r^2
+ * and the signed t = sum l r feed four mbLogC arguments only: el + er, max(el, er), es + ed and max(es, ed) with es = (el + er) + 2 t,
+ * ed = (el + er) - 2 t.  The kernels certify all four buckets from tree sums and intervals (the signed sum's half-width from
+ * sum |l r|) and run the strict loop otherwise.  Returns 0 = certified and equal to the strict buckets, 1 = not certified, 2 = WRONG. */
+static unsigned bucket(float x) { return f2u(x) >> 15; }
+static int metric_case(const float *l, const float *r, int n, int W, int l0, int shape)
+{
+    static float a[192], b[192], c[192], m[192];
+    volatile float el = 100.0f, er = 100.0f, t = 0.0f;
+    for (int k = 0; k < n; k++) {
+        volatile float x = l[k] * l[k], y = r[k] * r[k], z = l[k] * r[k];
+        a[k] = x; b[k] = y; c[k] = z; m[k] = fabsf(z);
+        el = el + x; er = er + y; t = t + z;
+    }
+    volatile float es = el + er, ed = es;
+    volatile float t2 = t + t;
+    es = es + t2; ed = ed - t2;
+    volatile float p1 = el + er, p3 = es + ed;
+    const float p2 = el > er ? el : er, p4 = es > ed ? es : ed;
+    /* the kernels' side: tree sums of the four term vectors */
+    const float SA = tree_sum(a, n, W, l0, shape), SB = tree_sum(b, n, W, l0, shape), SM = tree_sum(m, n, W, l0, shape);
+    float SC;
+    {   /* the signed sum through the same tree (tree_sum works on any floats) */
+        SC = tree_sum(c, n, W, l0, shape);
+    }
+    const float du = cert_delta(n + 1, W);       /* (the 100 in front is one more term, one more addition) */
+    volatile float tel = 100.0f + SA, ter = 100.0f + SB;
+    volatile float e1 = tel * du, e2 = ter * du, e3 = SM * du;
+    volatile float el_lo = tel - e1, el_hi = tel + e1, er_lo = ter - e2, er_hi = ter + e2;
+    /* (a sum of non-negative terms that starts at 100 never falls below 100: rounding is monotone) */
+    if (el_lo < 100.0f) el_lo = 100.0f;
+    if (er_lo < 100.0f) er_lo = 100.0f;
+    volatile float t_lo = SC - e3, t_hi = SC + e3;
+    volatile float tl2 = t_lo + t_lo, th2 = t_hi + t_hi;
+    volatile float p1_lo = el_lo + er_lo, p1_hi = el_hi + er_hi;
+    const float p2_lo = el_lo > er_lo ? el_lo : er_lo, p2_hi = el_hi > er_hi ? el_hi : er_hi;
+    volatile float es_lo = p1_lo + tl2, es_hi = p1_hi + th2, ed_lo = p1_lo - th2, ed_hi = p1_hi - tl2;
+    volatile float p3_lo = es_lo + ed_lo, p3_hi = es_hi + ed_hi;
+    float p4_lo = es_lo > ed_lo ? es_lo : ed_lo;
+    const float p4_hi = es_hi > ed_hi ? es_hi : ed_hi;
+    /* (one of es, ed is p1 plus something non-negative, rounded: max(es, ed) >= p1) */
+    if (p4_lo < p1_lo) p4_lo = p1_lo;
+    const int ok = p3_lo > 0.0f && p4_lo > 0.0f && bucket(p1_lo) == bucket(p1_hi) && bucket(p2_lo) == bucket(p2_hi) && bucket(p3_lo) == bucket(p3_hi) && bucket(p4_lo) == bucket(p4_hi);
+    /* the enclosures themselves must hold whether or not they certify */
+    if (!(el_lo <= el && el <= el_hi && er_lo <= er && er <= er_hi && t_lo <= t && t <= t_hi)) return 2;
+    if (!ok) return 1;
+    if (bucket(p1) != bucket(p1_lo) || bucket(p2) != bucket(p2_lo) || bucket(p3) != bucket(p3_lo) || bucket(p4) != bucket(p4_lo)) return 2;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const long N = argc > 1 ? atol(argv[1]) : 1000000;
     rng_s = argc > 2 ? strtoull(argv[2], 0, 10) * 2654435761u + 88172645463325252ull : 88172645463325252ull;
-    long bad = 0, straddle = 0, evals = 0, badq = 0, straddleq = 0;
+    long bad = 0, straddle = 0, evals = 0, badq = 0, straddleq = 0, badm = 0, straddlem = 0, evalm = 0;
     static float t[192], q[192];
     for (long it = 0; it < N; it++) {
         const int W = 2 + 2 * (int) (rnd() % 5);                       /* 2 .. 10 */
@@ -148,7 +199,33 @@ int main(int argc, char **argv)
             else if ((f2u(rs) >> 15) != (f2u(rl) >> 15)) { if (badq < 10) fprintf(stderr, "certified quotient bucket differs\n"); badq++; }
         }
     }
+    /* stereo metric: correlated channel pairs of every kind */
+    long kindm[8] = {0}, kindn[8] = {0};
+    for (long it = 0; it < N / 2; it++) {
+        static float l[192], r[192];
+        const int W = 2 + 2 * (int) (rnd() % 5);
+        int n = 2 * (1 + (int) (rnd() % 96));
+        if (n > 16 * W) n = 16 * W;
+        const int c = (n + W - 1) / W, l0 = (int) (rnd() % (65 - c)), shape = (int) (rnd() & 1);
+        const int kind = (int) (rnd() % 8);
+        const float scale = (float) pow(10.0, urand() * 9.0 - 3.0);
+        const double rho = kind == 0 ? 1.0 : kind == 1 ? -1.0 : kind == 2 ? 0.0 : kind == 3 ? 0.999 : kind == 4 ? -0.999 : urand() * 2.0 - 1.0;
+        for (int k = 0; k < n; k++) {
+            const double u = urand() * 2.0 - 1.0, v = urand() * 2.0 - 1.0;
+            double a = u, b = rho * u + (1.0 - fabs(rho)) * v;
+            if (kind == 6) { a = (k & 1) ? 0.0 : u; b = (k & 1) ? v : 0.0; }       /* disjoint support */
+            if (kind == 7) { a *= 1.0e-4; }                                         /* one channel nearly silent */
+            l[k] = (float) (a * scale); r[k] = (float) (b * scale);
+        }
+        const int res = metric_case(l, r, n, W, l0, shape);
+        evalm++;
+        if (res == 2) { if (badm < 10) fprintf(stderr, "metric: wrong certificate or enclosure, n %d W %d kind %d\n", n, W, kind); badm++; }
+        else if (res == 1) { straddlem++; kindm[kind]++; }
+        kindn[kind]++;
+    }
+    for (int k = 0; k < 8; k++) printf("  metric kind %d: not certified %.2f %%\n", k, 100.0 * kindm[k] / (kindn[k] ? kindn[k] : 1));
+    printf("metric bands %ld  wrong %ld  not certified %ld (%.3f %%)\n", evalm, badm, straddlem, 100.0 * straddlem / (evalm ? evalm : 1));
     printf("vectors %ld  outside %ld  straddles %ld (%.3f %%)  quotient outside %ld  quotient straddles %ld (%.3f %%)\n", evals, bad, straddle,
            100.0 * straddle / evals, badq, straddleq, 100.0 * straddleq / evals);
-    return (bad || badq) ? 1 : 0;
+    return (bad || badq || badm) ? 1 : 0;
 }

@@ -23,10 +23,14 @@ def checker(tmp_path_factory):
 def test_strict_sum_lies_inside_the_certified_interval(checker, seed):
     """>= 10^6 random and adversarial vectors of non-negative terms (n <= 192, runs of 2..10, wide dynamic range, subnormals,
     rounding-direction worst cases): the strict fp32 sum is inside [t (1 - c u), t (1 + c u)] of the kernels' tree sum t, a
-    certified mbLogC bucket is the strict sum's, and the same for the quotient of two sums"""
+    certified mbLogC bucket is the strict sum's, and the same for the quotient of two sums and for the four logarithms of the
+    stereo metric (k_spec: two non-negative sums that start at 100 and a signed one, whose interval comes from the sum of the
+    terms' magnitudes)"""
     r = subprocess.run([checker, "600000", str(seed)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "outside 0" in r.stdout and "quotient outside 0" in r.stdout, r.stdout
+    # the stereo metric's four certified buckets (signed sum included) on correlated channel pairs of every kind
+    assert "metric bands 300000  wrong 0 " in r.stdout, r.stdout
 
 
 RUN_CONFIGS = [dict(bitrate=64), dict(), dict(samprate=48000, vbr_mnr=100, hf_flag=3, freq_limit=19000), dict(samprate=32000, bitrate=64),
