@@ -1,5 +1,6 @@
-"""Nightly-style sweeps: python -m pytest tests -m gpu_long (about 20 minutes on one MI355X).  Not selected by -m gpu; without a
-GPU every test here skips.  The same tool the rounds' long sweeps use (tools/fuzz_parity.py), one fixed seed per slice."""
+"""Nightly-style sweeps: python -m pytest tests -m gpu_long (six minutes on one MI355X).  Only the 1000-case slice on the
+low-footprint build is also part of -m gpu (two minutes); without a GPU every test here skips.  The same tool the rounds' long
+sweeps use (tools/fuzz_parity.py), one fixed seed per slice."""
 import os
 import subprocess
 import sys
@@ -19,11 +20,16 @@ def _fuzz(args, env):
     assert r.returncode == 0 and ", 0 bad" in tail, tail + r.stderr[-500:]
 
 
-@pytest.mark.parametrize("build", ["slim", "fat"])
-def test_thousand_random_configurations_per_stream_walk_build(build):
-    """1000 random controls x random signals through random-sized calls on each build of the stream walk (the round-4 defect of
-    k_alloc_slim showed up at 2 in 3000)"""
-    _fuzz(["1000", "6001" if build == "slim" else "6002"], {"HMP3AMD_K6": build})
+@pytest.mark.gpu
+@pytest.mark.one_k6_build
+def test_thousand_random_configurations_on_the_low_footprint_build():
+    """1000 random controls x random signals through random-sized calls on k_alloc_slim (its round-4 defect showed up at 2 in
+    3000 cases, the in-suite slices were 60 - 120): part of -m gpu"""
+    _fuzz(["1000", "6001"], {"HMP3AMD_K6": "slim"})
+
+
+def test_thousand_random_configurations_on_the_four_stream_build():
+    _fuzz(["1000", "6002"], {"HMP3AMD_K6": "fat"})
 
 
 def test_hf_slice_on_the_low_footprint_build():
