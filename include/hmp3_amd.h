@@ -225,7 +225,11 @@ int hx_multi_encode_f32_host_stats(hx_multi *m, const float *pcm, int nframes, u
 int hx_multi_status(hx_multi *m);
 
 /* ---- test taps (tests only; synchronise) ---- */
-/* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg"; copies at most cap bytes, returns bytes */
+/* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg" (per-stage buffers), "ixq" "sgn" "seg" "frm" (what the allocator hands the
+   packer), "dur" (per-stream duration of the last allocator launch, 100 MHz ticks), "state", and two device counters (one int
+   each, running over the batch's calls): "big_sweeps" = noise passes that took the double-precision x^(4/3) table,
+   "strict_sums" = certified band sums that fell back to the reference's strict line-order sum (DESIGN.md section 2;
+   HMP3AMD_EXACT_SUMS=1 sends every sum there).  Copies at most cap bytes, returns bytes, -1 for an unknown name. */
 long long hx_batch_debug_read(hx_batch *b, const char *name, void *dst, long long cap);
 void hx_batch_debug_enable(hx_batch *b, int on);
 /* The first-generation allocator (intensity stereo, dual channel; reference bitallo1.cpp) calls libm's logf / log10f, which
