@@ -820,6 +820,29 @@ def test_config_4_share_at_full_length():
     b.close()
 
 
+@pytest.mark.one_k6_build
+@pytest.mark.parametrize("cfg", ["config3", "config5_share"])
+def test_configs_3_and_5_at_full_length_on_the_low_footprint_build(cfg, monkeypatch):
+    """BASELINE config 3 (4096 streams x 256 frames, VBR -V50, block switching) and one GPU's share of config 5 (32 / 44.1 / 48 kHz
+    by stream, CBR-128, correlation cycled) at their full size in one call on k_alloc_slim, the kernel bench.py runs them on:
+    48 distinct signals rotated in time, a 12-stream oracle subset byte for byte, every stream's status word"""
+    monkeypatch.setenv("HMP3AMD_K6", "slim")
+    a = api()
+    S, F, U = 4096, 256, 48
+    classes = [(dict(), 44100)] if cfg == "config3" else [(dict(bitrate=64, samprate=32000), 32000), (dict(bitrate=64), 44100), (dict(bitrate=64, samprate=48000), 48000)]
+    base = [synth.stream_pcm(9950 + u, F, sr=classes[u % len(classes)][1], rho=RHOS[u % 4], bursts=True) for u in range(U)]
+    pcm = np.stack([np.roll(base[i % U], 1152 * 5 * (i // U), axis=0) for i in range(S)])
+    ctl = [a.default_control(**classes[(i % U) % len(classes)][0]) for i in range(S)]
+    b = a.Batch(ctl if len(classes) > 1 else ctl[0], nstreams=S, max_frames=F)
+    assert b.k6_variant() == 1
+    got = b.encode_host(pcm)
+    assert b.status() == 0
+    rng = np.random.Generator(np.random.PCG64(13))
+    for s in rng.choice(S, 12, replace=False):
+        assert got[s] == oracle_bytes(classes[(s % U) % len(classes)][0], pcm[s], F), "stream %d" % s
+    b.close()
+
+
 def test_ragged_calls_equal_one_shot():
     """state carry across calls: 1 + 7 + 24 frames in three calls == 32 frames in one call"""
     kw = CONFIGS["vbr50_sw"]       # block switching on: the carry includes detector and block-type state
