@@ -143,21 +143,23 @@ def verify_streams(torch, np, wl, kws, pcm, out, nbytes, ids, steps_total):
     """byte-compare the last step's output of streams `ids` with the oracle; returns (n_ok, first bad id)"""
     import multiprocessing as mp
     F = pcm.shape[1] // 1152
-    host_pcm = pcm[torch.as_tensor(ids, device=pcm.device)].cpu().numpy()
-    host_out = out[torch.as_tensor(ids, device=out.device)].cpu().numpy()
     host_nb = nbytes.cpu().numpy()
-    jobs = [(kws[i], host_pcm[k], steps_total, F) for k, i in enumerate(ids)]
-    with mp.get_context("spawn").Pool(max(1, min(len(ids), os.cpu_count() or 1, 16))) as pool:
-        want = pool.map(_verify_worker, jobs)
     ok, bad = 0, None
-    for k, i in enumerate(ids):
-        got = host_out[k, :host_nb[i]].tobytes()
-        if got == want[k]:
-            ok += 1
-        elif bad is None:
-            n = min(len(got), len(want[k]))
-            diff = next((j for j in range(n) if got[j] != want[k][j]), n)
-            bad = {"stream": int(i), "bytes": len(got), "oracle_bytes": len(want[k]), "first_difference_at": diff}
+    # (--verify all: whole batches go through here, in blocks of 256 streams so that the host copies stay a few hundred MB)
+    with mp.get_context("spawn").Pool(max(1, min(len(ids), usable_cpus(), 32))) as pool:
+        for c0 in range(0, len(ids), 256):
+            blk = ids[c0:c0 + 256]
+            host_pcm = pcm[torch.as_tensor(blk, device=pcm.device)].cpu().numpy()
+            host_out = out[torch.as_tensor(blk, device=out.device)].cpu().numpy()
+            want = pool.map(_verify_worker, [(kws[i], host_pcm[k], steps_total, F) for k, i in enumerate(blk)], chunksize=1)
+            for k, i in enumerate(blk):
+                got = host_out[k, :host_nb[i]].tobytes()
+                if got == want[k]:
+                    ok += 1
+                elif bad is None:
+                    n = min(len(got), len(want[k]))
+                    diff = next((j for j in range(n) if got[j] != want[k][j]), n)
+                    bad = {"stream": int(i), "bytes": len(got), "oracle_bytes": len(want[k]), "first_difference_at": diff}
     return ok, bad
 
 
@@ -282,7 +284,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[n-1]")
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: the config's)")
-    ap.add_argument("--verify", type=int, default=16, help="streams checked against the CPU oracle after the timed region (0 = off)")
+    ap.add_argument("--verify", default="16", help="streams checked against the CPU oracle after the timed region: a number (0 = off) or 'all' (every stream of every rank's block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed pass on the correlation-cycled signal set (config 2, one GPU)")
     ap.add_argument("--host-fed", type=int, default=-1, help="1 / 0: also time (or not) the workload fed from page-locked host memory through the pipelined host-buffer calls; default: config 2 only")
@@ -294,6 +296,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="every rank on GPU 0 (tests on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous, sharding and reporting only, no encode (CPU test of the multi-rank path)")
     args = ap.parse_args()
+    try:
+        args.verify = (1 << 30) if str(args.verify).lower() == "all" else int(args.verify)      # (capped at the batch's streams where it is used)
+    except ValueError:
+        raise SystemExit("--verify takes a number or 'all'")
     if args.other_configs < 0:
         args.other_configs = 1 if args.config == 2 else 0
     if args.strong_scaling < 0:
@@ -437,6 +443,14 @@ def main():
         m = {"dt": dt, "status": batch.status(), "out_total": int(nbytes.sum().item())}
         m["k_ms"], m["k_calls"] = batch.alloc_kernel_ms()
         try:
+            # the tail the step is made of: every stream's own time inside the last timed step's allocator launch
+            # (device wall clock, 100 MHz ticks -> ms); a launch lasts as long as its slowest stream
+            d = batch.debug_read("dur", np.uint32, S).astype(np.float64) / 1e5
+            m["stream_ms"] = {"min": round(float(d.min()), 3), "mean": round(float(d.mean()), 3), "p50": round(float(np.percentile(d, 50)), 3),
+                              "p99": round(float(np.percentile(d, 99)), 3), "max": round(float(d.max()), 3), "streams": int(S), "frames": int(F)}
+        except Exception:           # an older build of the library (HMP3AMD_LIB)
+            m["stream_ms"] = None
+        try:
             m["k6"] = {"kernel": ("k_alloc_slim" if batch.k6_variant() == 1 else None), "resident_streams": batch.resident_streams()}
         except AttributeError:      # an older build of the library (HMP3AMD_LIB)
             m["k6"] = None
@@ -515,7 +529,7 @@ def main():
     for cfg in plan["other_configs"]:
         c = config_setup(cfg)
         pcm = synth_batch_gpu(torch, np, c["S"], c["F"], c["srs"], c["rhos"], c["wl"]["bursts"], dev, first_stream=c["first"])
-        mo = run(pcm, min(args.verify, 8) if world == 1 else (2 if args.verify > 0 else 0), c=c, steps=4, warmup=2)
+        mo = run(pcm, (args.verify if args.verify >= (1 << 30) else min(args.verify, 8)) if world == 1 else (2 if args.verify > 0 else 0), c=c, steps=4, warmup=2)
         # the same fed from page-locked host memory: the deployable rate of the configuration (PCIe both ways in the timed region)
         mo["host_fed"] = run_host_fed(pcm, c=c, steps_h=4) if cfg in plan["host_fed_configs"] else None
         del pcm
@@ -636,6 +650,8 @@ def main():
             res["roofline"]["stale_profile_file"] = prof[1]
         if valu is not None:
             res["roofline_issue"] = valu
+        # per-stream time inside the last timed step's allocator launch (ms): the launch - and at config 2 the step - ends with "max"
+        res["stream_ms"] = m.get("stream_ms")
         if ver_n:
             res["verified_streams"] = ver_ok
             res["verify"] = {"checked": ver_n, "identical": ver_ok, "first_mismatch": m.get("verify_bad"),
@@ -645,7 +661,7 @@ def main():
         if worst is not None:
             res["worst_case_value"] = round(S * F * args.steps / worst["dt"], 1)
             res["worst_case"] = {"signal": "inter-channel correlation cycled over {0.7, 0, 1, 0.3} by stream", "ms_per_step": round(worst["dt"] / args.steps * 1e3, 3),
-                                 "kernel_ms": round(worst["k_ms"], 3), "kernel_status": worst["status"]}
+                                 "kernel_ms": round(worst["k_ms"], 3), "kernel_status": worst["status"], "stream_ms": worst.get("stream_ms")}
         if m.get("k6"):
             res["roofline"]["resident_streams"] = m["k6"]["resident_streams"]
         try:        # which C library the checker on this box runs on (matters for first-generation-allocator streams only: hx_libm32.h)
@@ -662,7 +678,7 @@ def main():
                            "steps": 4, "warmup": 2, "ms_per_step": round(mo["dt"] / 4 * 1e3, 3), "kernel_ms": round(mo["k_ms"], 3),
                            "kernel_build": (mo["k6"]["kernel"] if mo.get("k6") and mo["k6"]["kernel"] else "k_alloc"),
                            "resident_streams": mo["k6"]["resident_streams"] if mo.get("k6") else None,
-                           "roofline_frac": round(ach_o / HBM_PEAK_GBS, 6) if ach_o else None,
+                           "roofline_frac": round(ach_o / HBM_PEAK_GBS, 6) if ach_o else None, "stream_ms": mo.get("stream_ms"),
                            "verified_streams": mo.get("verified_all", mo.get("verified")), "verify_checked": mo.get("verify_n_all", mo.get("verify_n")),
                            "kernel_status": mo.get("status_all", mo["status"]), "host_fed": mo.get("host_fed")})
             res["other_configs"] = oc

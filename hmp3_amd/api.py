@@ -51,7 +51,7 @@ EXPORTS = [
     "hx_batch_gate_timeouts", "hx_enc_out_stats", "hx_multi_create", "hx_multi_destroy", "hx_multi_ndevices", "hx_multi_nstreams", "hx_multi_shard", "hx_multi_batch",
     "hx_multi_out_stride", "hx_multi_encode_s16_host", "hx_multi_encode_f32_host", "hx_multi_encode_f32_host_stats", "hx_multi_status",
     "hx_build_id", "hx_batch_frames_bytes", "hx_batch_alloc_kernel_ms", "hx_batch_debug_read", "hx_batch_debug_enable", "hx_debug_host_table",
-    "hx_batch_k6_variant", "hx_batch_resident_streams", "hx_debug_slim_tables_ok", "hx_libc_version", "hx_libm_spot_check", "hx_device_numa_node", "hx_bind_thread_to_device", "hx_bind_thread_to_node",
+    "hx_batch_k6_variant", "hx_batch_resident_streams", "hx_debug_slim_tables_ok", "hx_libc_version", "hx_libm_spot_check", "hx_device_numa_node", "hx_bind_thread_to_device", "hx_bind_thread_to_node", "hx_refresh_process_cpus",
 ]
 
 _lib = None
@@ -184,6 +184,11 @@ def device_numa_node(device):
 def bind_thread_to_device(device):
     """restrict the calling thread to the CPUs of the device's NUMA node; returns their number (0: nothing changed)"""
     return int(lib().hx_bind_thread_to_device(int(device)))
+
+
+def refresh_process_cpus():
+    """re-capture the CPUs the process may use (after a launcher narrowed it); returns their number"""
+    return int(lib().hx_refresh_process_cpus())
 
 
 def bind_thread_to_node(node):

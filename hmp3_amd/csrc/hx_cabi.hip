@@ -237,7 +237,12 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
         for (size_t i = 0; i < seen.size(); i++) if (memcmp(&seen[i], c, sizeof(HxControl)) == 0) { k = (int) i; break; }
         if (k < 0) {
             HxParams p;
-            if (!hx_resolve(c, &p)) { set_err("configuration rejected (the reference's L3_audio_encode_init returns 0 for it)"); delete b; return nullptr; }
+            if (!hx_resolve(c, &p)) {
+                // (a limit of this library's layout is named as such: the reference would have taken the configuration)
+                if (*hx_resolve_error()) set_err("configuration rejected: %s", hx_resolve_error());
+                else set_err("configuration rejected (the reference's L3_audio_encode_init returns 0 for it)");
+                delete b; return nullptr;
+            }
             if (p.filter_dc) b->any_dc = true;
             if (b->params.empty()) { b->nchan = p.nchan; b->lsf = p.h_id ? 0 : 1; b->alloc1 = p.alloc1; }
             else if (p.alloc1 != b->alloc1) { set_err("intensity-stereo / dual-channel streams (first-generation allocator) cannot share a batch with the others"); delete b; return nullptr; }
@@ -1086,7 +1091,7 @@ extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
 {
     if (e->b) { hx_batch_destroy(e->b); e->b = nullptr; }       // re-init is legal (mp3enc.cpp:267-272)
     int r = hx_resolve((const HxControl *) ec, &e->p);
-    if (!r) { set_err("configuration rejected"); return 0; }
+    if (!r) { if (*hx_resolve_error()) set_err("configuration rejected: %s", hx_resolve_error()); else set_err("configuration rejected"); return 0; }
     e->b = hx_batch_create(e->device, 1, ec, 1, 1);
     if (!e->b) return 0;
     e->frames = e->bytes = 0; e->ave = 0;
@@ -1316,6 +1321,19 @@ __attribute__((constructor)) static void capture_process_cpus()
     CPU_ZERO(&g_proc_cpus);
     g_proc_cpus_ok = sched_getaffinity(0, sizeof(g_proc_cpus), &g_proc_cpus) == 0;
 }
+// A process whose CPU set changes after the library was loaded (a launcher that calls sched_setaffinity / taskset on the
+// running process, a cpuset change; in Python the library loads lazily, so "when it was loaded" depends on import order)
+// takes the set again from its main thread's current mask: returns the number of CPUs, 0 on failure.  The bind calls also
+// do this once by themselves when the kernel refuses the mask they computed (EINVAL: none of its CPUs is allowed any more).
+extern "C" int hx_refresh_process_cpus(void)
+{
+    cpu_set_t now;
+    CPU_ZERO(&now);
+    if (sched_getaffinity(getpid(), sizeof(now), &now) != 0) return 0;      // (pid = the main thread's id)
+    g_proc_cpus = now;
+    g_proc_cpus_ok = true;
+    return CPU_COUNT(&now);
+}
 
 // the CPUs of a node that this process may use: parses /sys/devices/system/node/node<N>/cpulist ("0-15,128-143")
 static int node_cpus_allowed(int node, cpu_set_t *out)
@@ -1346,7 +1364,11 @@ extern "C" int hx_bind_thread_to_node(int node)
 {
     if (node < 0) return 0;
     cpu_set_t set;
-    const int n = node_cpus_allowed(node, &set);
+    int n = node_cpus_allowed(node, &set);
+    if (n > 0 && sched_setaffinity(0, sizeof(set), &set) == 0) return n;
+    // the process's CPU set may have been narrowed since it was captured: take it again, try once more
+    if (hx_refresh_process_cpus() <= 0) return 0;
+    n = node_cpus_allowed(node, &set);
     if (n <= 0) return 0;
     return sched_setaffinity(0, sizeof(set), &set) == 0 ? n : 0;
 }

@@ -382,7 +382,15 @@ static int cut_runs(const int *width, const int *first, int nb, int wmin, int wm
 {
     for (int W = wmin; W <= wmax; W += 2) {
         int lanes = 0, ok = 1;
-        for (int b = 0; b < nb; b++) { const int c = (width[b] + W - 1) / W; if (c > maxl) ok = 0; lanes += c; }
+        for (int b = 0; b < nb; b++) {
+            const int c = (width[b] + W - 1) / W;
+            if (c > maxl) ok = 0;
+            lanes += c;
+            // The kernels read a lane's operands as W / 2 pairs from the run's first line whatever its length (sweep_load,
+            // sweep_run_stored, isf2_run, msmetric_unit drop what lies past the run): the last run of a band may start up to
+            // W - 2 lines before the band's end, so every run must satisfy start + W <= 576 to stay inside the channel's array.
+            if (c > 0 && first[b] + (c - 1) * W + W > 576) ok = 0;
+        }
         if (!ok || lanes > nlanes) continue;
         int l = lane0;
         for (int b = 0; b < nb; b++) {
@@ -398,15 +406,29 @@ static int cut_runs(const int *width, const int *first, int nb, int wmin, int wm
     return 0;
 }
 
+// Why the last hx_resolve of this thread returned 0 although the reference would accept the configuration: a limit of this
+// library's kernel layout, not of the format ("" = the reference rejects it too).  hx_batch_create / hx_enc_* put it into
+// hx_last_error().
+static thread_local const char *g_resolve_why = "";
+const char *hx_resolve_error(void) { return g_resolve_why; }
+
 static int band_runs(HxParams *p)
 {
     memset(p->lane_run, 0, sizeof(p->lane_run));
     memset(p->band_last_lane, 0, sizeof(p->band_last_lane));
     // (every long band starts on an even line and has an even width: ISO Table B.8; the packed form relies on it)
-    for (int b = 0; b < 22; b++) if ((p->startBand_l[b] | p->nBand_l[b]) & 1) return 0;
+    for (int b = 0; b < 22; b++) if ((p->startBand_l[b] | p->nBand_l[b]) & 1) {
+        g_resolve_why = "kernel layout limit: a long scalefactor band starts on an odd line or has an odd width (line runs are stored as pairs)";
+        return 0;
+    }
     const int nb = MX(p->nsf[0], p->nchan == 2 ? p->nsf[1] : 0);
     p->run_w = cut_runs(p->nBand_l, p->startBand_l, nb, 2, 10, 16, 0, 64, p->lane_run, p->band_last_lane);
-    if (nb > 0 && !p->run_w) return 0;
+    if (nb > 0 && !p->run_w) {
+        // (32 kHz with all 21 bands measured takes exactly 64 of the 64 lanes at W = 10: tests/test_cert_sums.py pins it)
+        g_resolve_why = "kernel layout limit: the measured scalefactor bands do not fit 64 lanes in runs of at most 10 lines with at most 16 lanes per band "
+                        "(hx_host.cpp band_runs; the certified band sums of the stream walk need one run per lane)";
+        return 0;
+    }
     return 1;
 }
 
@@ -416,6 +438,7 @@ int hx_resolve(const HxControl *ec_arg, HxParams *p)
     static const int mnrGOLD[22] = {-5, 0, 0, 0, 0, 0, 0, 0, 0, 3, 5, 5, 5, 5, 3, 0, 0, 0, -1, -8, -10, 0};
     HxControl ec = *ec_arg;
     memset(p, 0, sizeof(*p));
+    g_resolve_why = "";
     if (ec.mode < 0) ec.mode = 1;
     if (ec.mode > 3) ec.mode = 3;
     if (ec.bitrate < 0) { ec.bitrate = 64; if (ec.samprate < 32000) ec.bitrate = 32; }

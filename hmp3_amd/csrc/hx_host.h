@@ -4,6 +4,9 @@
 void hx_host_default_control(HxControl *ec);
 void hx_global_tabs(HxGlobalTabs *g);
 int hx_resolve(const HxControl *ec, HxParams *p);
+// after hx_resolve returned 0 on this thread: "" if the reference rejects the configuration too, else the limit of this
+// library's kernel layout that it ran into (hx_host.cpp band_runs)
+const char *hx_resolve_error(void);
 void hx_stream_reset(const HxParams *p, int cls, HxStream *s);
 // 1 if these tables have the structure the low-footprint allocator kernel (k_alloc_slim) derives them from: the gain tables
 // as ldexp of their 4 / 16 mantissas, the x^(3/4) exponent table likewise, the mB tables within 16 bits (hx_alloc.hip, HX_SLIM)

@@ -205,6 +205,11 @@ float hx_batch_alloc_kernel_ms(hx_batch *b, int *ncalls);
 int hx_device_numa_node(int device);
 int hx_bind_thread_to_device(int device);
 int hx_bind_thread_to_node(int node);
+/* The process's CPU set is captured when the library is loaded.  A process that is narrowed or moved afterwards (taskset -p,
+   os.sched_setaffinity by a launcher, a cpuset change) calls this from any thread to take the set again from its main
+   thread's current mask; returns the number of CPUs (0 = failed, nothing changed).  The bind calls retry with it once by
+   themselves when the kernel rejects the mask they computed from the stale set. */
+int hx_refresh_process_cpus(void);
 
 /* ---- several GPUs of one node behind one handle (no reference equivalent) ----
    nstreams independent streams in contiguous blocks over ndev devices (devices[0..ndev), or devices

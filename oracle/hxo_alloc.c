@@ -757,6 +757,11 @@ static void trade_dual(ba_t *b)
     }
 }
 
+/* Rate-loop path statistics for the tools (tools/oracle_rate_stats.py): [0] granules allocated, [1] granules that entered
+   increase_bits past its threshold test, [2] its first-pass iterations, [3] its step-backs, [4] granules that entered
+   decrease_bits, [5] its rounds, [6] limit_bits rounds, [7] quantise-and-count passes in all.  Not part of the encoder. */
+long long hxo_rate_stats[8];
+
 /* bitallo3.cpp:2569-2722 */
 static int increase_bits(ba_t *b, int bits0, int ms)
 {
@@ -764,9 +769,11 @@ static int increase_bits(ba_t *b, int bits0, int ms)
     hxo_state *st = &b->e->s;
     int i, k, ch, bits = bits0, g[2][22], thres = b->minTargetBits - (b->minTargetBits >> 4), pass;
     if (bits0 > thres) return bits0;
+    hxo_rate_stats[1]++;
     for (ch = 0; ch < 2; ch++) for (i = 0; i < p->nsf[ms ? 0 : ch]; i++) g[ch][i] = b->gsf[ch][i];
     for (pass = 0; pass < 2; pass++) {
         for (k = 0; k < (pass ? 1 : 10); k++) {
+            hxo_rate_stats[pass ? 3 : 2]++; hxo_rate_stats[7]++;
             for (ch = 0; ch < b->nchan; ch++)
                 for (i = 0; i < p->nsf[ch]; i++) {
                     if (pass) b->gsf[ch][i] = g[ch][i] + 1;
@@ -804,7 +811,9 @@ static int decrease_bits(ba_t *b, int bits0)
     deltaN = (f * (bits0 - b->maxTargetBits)) >> 10;
     deltaN = HXO_MAX(deltaN, 40);
     b->deltaMNR = 0;
+    hxo_rate_stats[4]++;
     for (k = 0; k < 10; k++) {
+        hxo_rate_stats[5]++; hxo_rate_stats[7]++;
         b->deltaMNR += deltaN;
         for (ch = 0; ch < b->nchan; ch++) for (i = 0; i < p->nsf[ch]; i++) b->NT[ch][i] += deltaN;
         seek_actual(b);
@@ -825,6 +834,7 @@ static int limit_bits(ba_t *b, int part23)
     hxo_state *st = &b->e->s;
     int i, k, ch, bits = 0;
     for (k = 0; k < 100; k++) {
+        hxo_rate_stats[6]++; hxo_rate_stats[7]++;
         for (ch = 0; ch < b->nchan; ch++) {
             if (part23 && st->huff_bits[ch] <= PART23) continue;
             for (i = 0; i < p->nsf[ch]; i++) b->gsf[ch][i] = HXO_MIN(127, b->gsf[ch][i] + 1);
@@ -880,6 +890,7 @@ static int allocate(ba_t *b, int ms)
     scale_factors(b, ms);
     big_lucky_noise(b);
     do_quant(b, 1);
+    hxo_rate_stats[0]++; hxo_rate_stats[7]++;
     if (ms) { st->ixmax[0][21] = 0; if (st->hf_quant) quant_hf_ms(b); bits0 = bits = count_bits(b); }
     else { if (st->hf_quant) quant_hf(b); bits0 = bits = count_bits_dual(b); }
     if (bits < b->minTargetBits && st->MNR < 2000) bits = increase_bits(b, bits, ms);

@@ -92,3 +92,30 @@ def test_line_runs_tile_the_measured_bands(kw):
             assert int(run[l]) == 0
 
     check(run, [last], [(0, b) for b in range(nb)], W, 0)
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="hmp3_amd/libhmp3amd.so not built (hmp3_amd/build.sh)")
+def test_the_tightest_rate_uses_all_64_lanes_and_no_run_reads_past_the_spectrum():
+    """32 kHz with all 21 long bands measured is the layout's edge: runs of W = 10 lines take exactly 64 of the 64 lanes
+    (hx_host.cpp band_runs).  Pinned so that a change of the band tables, of nsf or of the run rules that pushes it over shows
+    up here as a named failure and not as hx_batch_create returning null; and for every supported rate the kernels' unconditional
+    pair reads from a run's first line (sweep_load, isf2_run, msmetric_unit: W lines whatever the run's length) stay inside the
+    channel's 576 lines."""
+    from hmp3_amd import api
+
+    def tab(ec, name, dtype, count):
+        a = np.zeros(count, dtype)
+        n = api.lib().hx_debug_host_table(C.byref(ec), name.encode(), a.ctypes.data, a.nbytes)
+        assert n == a.nbytes, (name, api.last_error())
+        return a
+    ec = api.default_control(samprate=32000, bitrate=64)
+    W = int(tab(ec, "run_w", np.int32, 1)[0])
+    run = tab(ec, "lane_run", np.uint16, 64)
+    used = sum(1 for r in run if (int(r) >> 9) & 7)
+    assert (W, used) == (10, 64), "32 kHz: W = %d, %d lanes used (the layout's edge moved)" % (W, used)
+    for kw in RUN_CONFIGS:
+        ec = api.default_control(**kw)
+        W = int(tab(ec, "run_w", np.int32, 1)[0])
+        for r in tab(ec, "lane_run", np.uint16, 64):
+            if (int(r) >> 9) & 7:
+                assert (int(r) & 511) * 2 + W <= 576, kw

@@ -176,3 +176,39 @@ def test_a_thread_bound_to_one_node_can_be_bound_to_another():
         assert api.bind_thread_to_node(-1) == 0 and os.sched_getaffinity(0) == want      # unknown node: left as it was
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_a_process_narrowed_after_the_library_was_loaded_is_followed():
+    """The CPU set the bind calls intersect a node's list with is captured when the library is loaded; a process that is narrowed
+    afterwards (taskset -p, a launcher's sched_setaffinity) has hx_refresh_process_cpus to take it again, and a bind whose mask
+    the kernel refuses retries with the refreshed set by itself (round 5's advisor finding).  Runs in a child process: the
+    main thread's mask is what is re-read, and pytest's own must stay as it is."""
+    import subprocess, sys, textwrap
+    if not hasattr(os, "sched_getaffinity") or not os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        pytest.skip("no sysfs NUMA description on this host")
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        from hmp3_amd import api
+        api.lib()                                   # loaded with the full mask
+        full = os.sched_getaffinity(0)
+        spec = open("/sys/devices/system/node/node0/cpulist").read().strip()
+        node0 = set()
+        for part in spec.split(","):
+            a, _, z = part.partition("-")
+            node0 |= set(range(int(a), int(z or a) + 1))
+        want = sorted(node0 & full)
+        if len(want) < 3:
+            print("SKIP"); sys.exit(0)
+        narrow = set(want[:2])
+        os.sched_setaffinity(0, narrow)             # the main thread = the process, as a launcher would
+        assert api.refresh_process_cpus() == 2
+        os.sched_setaffinity(0, {want[0]})
+        assert api.bind_thread_to_node(0) == 2 and os.sched_getaffinity(0) == narrow, os.sched_getaffinity(0)
+        print("OK")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    if "SKIP" in r.stdout:
+        pytest.skip("fewer than three usable CPUs on node 0")
+    assert "OK" in r.stdout

@@ -10,7 +10,17 @@ ngen=${3:-1500}; nhf=${4:-1000}; nsub=${5:-400}; nmix=${6:-60}; soak=${7:-6000};
 mkdir -p gpurun_out
 exec > gpurun_out/${label}_sweeps.log 2>&1
 python -c "from hmp3_amd import api; print('build', api.build_id())"
-run() { echo "== $*"; "$@" 2>&1 | grep -v amdgpu.ids | tail -4; }
+# every slice's exit status is recorded (rc=N; 124 = killed by timeout) and its summary line must say ", 0 bad" (the soak: a line ending in "ok"):
+# a slice that crashed or was cut short marks the whole log FAILED and the script exits non-zero
+fail=0
+run() {
+  echo "== $*"
+  local t; t=$(mktemp)
+  "$@" > "$t" 2>&1; local rc=$?
+  grep -v amdgpu.ids "$t" | tail -4
+  if [ $rc -ne 0 ] || ! grep -qE ", 0 bad| ok$" "$t"; then echo "rc=$rc FAILED: $*"; fail=1; else echo "rc=0"; fi
+  rm -f "$t"
+}
 for v in slim fat; do
   export HMP3AMD_K6=$v
   [ $ngen -gt 0 ] && run timeout 3000 python tools/fuzz_parity.py $ngen $((seed + 1))
@@ -22,4 +32,5 @@ done
 unset HMP3AMD_K6
 [ $nmix -gt 0 ] && run timeout 1500 python tools/fuzz_mixed.py $nmix $((seed + 5))
 [ $soak -gt 0 ] && HMP3AMD_K6=slim run timeout 1500 python tools/soak.py $soak
+if [ $fail -ne 0 ]; then echo "== FAILED (at least one slice did not finish clean)"; exit 1; fi
 echo "== done"
