@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed pass on the correlation-cycled signal set (config 2, one GPU)")
     ap.add_argument("--host-fed", type=int, default=-1, help="1 / 0: also time (or not) the workload fed from page-locked host memory through the pipelined host-buffer calls; default: config 2 only")
     ap.add_argument("--other-configs", type=int, default=-1, help="1 / 0: also run the other BASELINE configs at full width for 4 timed steps each and append them as other_configs (one GPU: 3, 4, 5; several: 4 and 5, the configs BASELINE defines on 8 GPUs), each with its host-fed rate; default: with config 2 at its own size")
+    ap.add_argument("--other-size", default="", help="S,F: run the other_configs (and their host-fed passes) at this reduced size per GPU instead of their full width, also next to --streams / --frames (the multi-GPU pre-flight test: everything of an 8-rank run except the devices)")
     ap.add_argument("--strong-scaling", type=int, default=-1, help="1 / 0: with --gpus N > 1 also time config 2's 1024 streams split N ways (strong scaling, SURVEY 8e); default: with config 2 at its own size")
     ap.add_argument("--no-pipeline", action="store_true", help="plain hx_batch_encode_s16_device calls instead of submit / wait")
     ap.add_argument("--gate", type=int, default=-1, help="hx_batch_set_gate percent (library default)")
@@ -301,13 +302,16 @@ def main():
     except ValueError:
         raise SystemExit("--verify takes a number or 'all'")
     if args.other_configs < 0:
-        args.other_configs = 1 if args.config == 2 else 0
+        args.other_configs = 1 if (args.config == 2 or args.other_size) else 0
     if args.strong_scaling < 0:
         args.strong_scaling = 1 if (args.config == 2 and args.gpus > 1 and not args.streams and not args.frames) else 0
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     # what the line will carry beside `value` (also printed by --dry-run, so that the multi-rank CPU tests can check the plan)
-    plan_other = [c for c in ((3, 4, 5) if args.gpus == 1 else (4, 5)) if c != args.config] if (args.other_configs and not args.streams and not args.frames) else []
+    other_size = tuple(int(x) for x in args.other_size.split(",")) if args.other_size else ()
+    if other_size and (len(other_size) != 2 or min(other_size) < 1):
+        raise SystemExit("--other-size takes S,F")
+    plan_other = [c for c in ((3, 4, 5) if args.gpus == 1 else (4, 5)) if c != args.config] if (args.other_configs and ((not args.streams and not args.frames) or other_size)) else []
     plan = {"other_configs": plan_other, "host_fed_configs": ([args.config] if (args.host_fed == 1 or (args.host_fed < 0 and args.config == 2)) else []) + (plan_other if args.host_fed != 0 else []),
             "strong_scaling": bool(args.strong_scaling and args.gpus > 1), "worst_case": bool(args.config == 2 and args.gpus == 1 and not args.no_worst_case)}
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -527,7 +531,7 @@ def main():
     # ---- the other BASELINE configurations at full width, a few steps each: reported beside `value`, never as it ----
     others = []
     for cfg in plan["other_configs"]:
-        c = config_setup(cfg)
+        c = config_setup(cfg, *other_size)
         pcm = synth_batch_gpu(torch, np, c["S"], c["F"], c["srs"], c["rhos"], c["wl"]["bursts"], dev, first_stream=c["first"])
         mo = run(pcm, (args.verify if args.verify >= (1 << 30) else min(args.verify, 8)) if world == 1 else (2 if args.verify > 0 else 0), c=c, steps=4, warmup=2)
         # the same fed from page-locked host memory: the deployable rate of the configuration (PCIe both ways in the timed region)
@@ -549,7 +553,7 @@ def main():
     if plan["strong_scaling"]:
         wl2 = workload(2)
         f2, l2 = shard.shard_range(wl2["S"], world, rank)
-        cs = dict(cfg=2, wl=wl2, S=l2 - f2, F=wl2["F"], first=f2, ncls=1, kws=[wl2["classes"][0][0]] * (l2 - f2),
+        cs = dict(cfg=2, wl=wl2, S=l2 - f2, F=(other_size[1] if other_size else wl2["F"]), first=f2, ncls=1, kws=[wl2["classes"][0][0]] * (l2 - f2),
                   srs=[wl2["classes"][0][1]] * (l2 - f2), rhos=[wl2["rho"][0]] * (l2 - f2))
         pcm = synth_batch_gpu(torch, np, cs["S"], cs["F"], cs["srs"], cs["rhos"], False, dev, first_stream=f2)
         ms_ = run(pcm, 2 if args.verify > 0 else 0, c=cs, steps=8, warmup=2)

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <chrono>
+#include <atomic>
 #include <string>
 #include "../../include/hmp3_amd.h"
 #include "hx_types.h"
@@ -142,6 +144,7 @@ struct hx_batch {
     // Not 100: the gate's own wavefront holds register space on one SIMD, so the last allocator workgroup of a full
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
+    bool capturing = false;             // the pass is being recorded into a HIP graph (hx_enc_*): no timing events, nothing that queries the stream
     bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
     // longest-first workgroup order: 2 = for every batch with more streams than the chip has CUs (default: below that no two
     // streams share a CU and the order decides nothing), 3 = always (tests), 1 = only for batches beyond the resident set,
@@ -650,16 +653,20 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.ixq = x_ixq; a.sgn_w = x_sgn; a.seg = x_seg; a.frm = x_frm; a.slots = x_slots;
     a.pre_len = x_prelen; a.carry_len = x_carrylen;
     b->alloc_launches++;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, qa));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!b->capturing) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, qa));
+    }
     if (b->alloc1) { if (b->lsf) LAUNCH_LDS(k_alloc1_lsf, dim3(S), dim3(128), K6_LDS(k_alloc1_lsf), qa, a); else LAUNCH_LDS(k_alloc1, dim3(S), dim3(128), K6_LDS(k_alloc1), qa, a); }
     else if (b->lsf) LAUNCH_LDS(k_alloc_lsf, dim3(S), dim3(128), K6_LDS(k_alloc_lsf), qa, a);
     else if (b->slim) LAUNCH_LDS(k_alloc_slim, dim3(S), dim3(128), K6_LDS(k_alloc_slim), qa, a);
     else LAUNCH_LDS(k_alloc, dim3(S), dim3(128), K6_LDS(k_alloc), qa, a);
-    HIPCHK(hipEventRecord(e1, qa));
-    b->pending.push_back({e0, e1});
+    if (!b->capturing) {
+        HIPCHK(hipEventRecord(e1, qa));
+        b->pending.push_back({e0, e1});
+    }
     // Every frame of the call packed at once, between the pending frames' images coming out of the stream state and the
     // incomplete ones' going back in.  A plain call (and a host-buffer submit) packs right behind its allocator launch.  A
     // device-buffer submit leaves its packing for later: it is enqueued on a stream of its own behind the NEXT submit's
@@ -678,7 +685,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         if (enqueue_pack(b, d_out, out_stride, d_out_bytes, nframes, set, sset, qa) != 0) return -1;
         if (pipelined) { HIPCHK(hipEventRecord(b->ev_alloc[set], qa)); HIPCHK(hipEventRecord(b->ev_sgn[sset], qa)); }
     }
-    while (b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events
+    while (!b->capturing && b->pending.size() > 512) {       // a caller that never asks for the timings must not accumulate events
         const auto old = b->pending.front();
         if (hipEventQuery(old.second) != hipSuccess) break;
         float ms = 0;
@@ -1068,7 +1075,32 @@ struct hx_enc {
     hx_src *src = nullptr;              // converter of the MP3_audio_encode entry points
     unsigned char *d_packet = nullptr;  // one reformatted frame (device), allocated on first *_Packet call
     int *d_packet_bytes = nullptr;
+    // One call = one graph launch: the whole single-stream chain (PCM up, the pipeline's kernels, byte count / frame counter /
+    // bitstream down) is recorded once into a HIP graph over page-locked staging buffers and replayed per call
+    // (reference call being replaced: CMp3Enc::L3_audio_encode, mp3enc.cpp:2031-2073, and MP3_audio_encode, :2812-2866).
+    hipStream_t gq = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    float *h_pcm = nullptr;             // page-locked: one 1152-sample block, float at int16 scale
+    unsigned char *h_out = nullptr;     // page-locked: the head of the call's output (HX_ENC_GRAPH_HEAD bytes; the rest is fetched when a call emits more)
+    unsigned *h_meta = nullptr;         // page-locked: [0] bytes emitted by the call, [1] the stream's frame counter, [2] allocator launches so far (the graph's last copy: changes with every replay)
+    int graph_state = 0;                // 0 = not built yet, 1 = ready, -1 = not available (disabled, or the build failed: plain calls)
+    bool spin_off = false;              // HMP3AMD_ENC_GRAPH=2: always wait with hipStreamSynchronize (A/B of the wait)
+    int plain_calls = 0;                // calls made the plain way since init (the first ones: they also load the kernels' code objects)
 };
+#define HX_ENC_GRAPH_HEAD 8192
+
+static void enc_graph_drop(hx_enc *e)
+{
+    if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    if (e->gq) { hipStreamDestroy(e->gq); e->gq = nullptr; }
+    if (e->h_pcm) { hipHostFree(e->h_pcm); e->h_pcm = nullptr; }
+    if (e->h_out) { hipHostFree(e->h_out); e->h_out = nullptr; }
+    if (e->h_meta) { hipHostFree(e->h_meta); e->h_meta = nullptr; }
+    e->graph_state = 0;
+    e->plain_calls = 0;
+}
 
 extern "C" hx_enc *hx_enc_create(int device)
 {
@@ -1080,6 +1112,7 @@ extern "C" hx_enc *hx_enc_create(int device)
 extern "C" void hx_enc_destroy(hx_enc *e)
 {
     if (!e) return;
+    enc_graph_drop(e);
     if (e->d_packet) hipFree(e->d_packet);
     if (e->d_packet_bytes) hipFree(e->d_packet_bytes);
     hx_src_destroy(e->src);
@@ -1089,6 +1122,7 @@ extern "C" void hx_enc_destroy(hx_enc *e)
 
 extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
 {
+    enc_graph_drop(e);
     if (e->b) { hx_batch_destroy(e->b); e->b = nullptr; }       // re-init is legal (mp3enc.cpp:267-272)
     int r = hx_resolve((const HxControl *) ec, &e->p);
     if (!r) { if (*hx_resolve_error()) set_err("configuration rejected: %s", hx_resolve_error()); else set_err("configuration rejected"); return 0; }
@@ -1101,10 +1135,99 @@ extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
     return r;
 }
 
+// Record the single-stream chain of e->b into a graph (see hx_enc).  Returns 0 when e->gexec is ready.
+static int enc_graph_build(hx_enc *e)
+{
+    hx_batch *b = e->b;
+    HIPCHK(hipSetDevice(b->device));
+    const long long stride = (long long) e->outbuf.size();
+    const long long pbytes = 1152LL * b->nchan * (long long) sizeof(float), obytes = stride;
+    // the staging the host-buffer calls use, allocated before the capture starts (no allocation inside one)
+    if (pbytes > b->pcm_cap) { if (b->d_pcm) hipFree(b->d_pcm); HIPCHK(hipMalloc((void **) &b->d_pcm, pbytes)); b->pcm_cap = pbytes; }
+    if (obytes > b->out_cap) { if (b->d_out) hipFree(b->d_out); HIPCHK(hipMalloc((void **) &b->d_out, obytes)); b->out_cap = obytes; }
+    HIPCHK(hipHostMalloc((void **) &e->h_pcm, (size_t) pbytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &e->h_out, HX_ENC_GRAPH_HEAD, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &e->h_meta, 4 * sizeof(unsigned), hipHostMallocDefault));
+    e->h_meta[0] = e->h_meta[1] = 0;
+    HIPCHK(hipMemcpy(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIPCHK(hipStreamCreateWithFlags(&e->gq, hipStreamNonBlocking));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamBeginCapture(e->gq, hipStreamCaptureModeThreadLocal));
+    int r = 0;
+    b->capturing = true;
+    if (hipMemcpyAsync(b->d_pcm, e->h_pcm, (size_t) pbytes, hipMemcpyHostToDevice, e->gq) != hipSuccess) r = -1;
+    if (!r) r = encode_core(b, nullptr, (const float *) b->d_pcm, 1, b->d_out, stride, b->d_outbytes, e->gq);
+    b->capturing = false;
+    if (!r && hipMemcpyAsync(&e->h_meta[0], b->d_outbytes, sizeof(int), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    if (!r && hipMemcpyAsync(&e->h_meta[1], (char *) b->d_st + offsetof(HxStream, tot_frames_out), sizeof(unsigned), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    const size_t head = (size_t) (stride < HX_ENC_GRAPH_HEAD ? stride : HX_ENC_GRAPH_HEAD);
+    if (!r && hipMemcpyAsync(e->h_out, b->d_out, head, hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    // last node: the count of allocator workgroups started so far (one more per call of a one-stream batch).  The copies of a
+    // recorded stream run in order, so when this word changes in host memory the call's other results have landed.
+    if (!r && hipMemcpyAsync(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(e->gq, &g);       // (always ended, also after a failure inside)
+    if (r || ce != hipSuccess || !g) { if (g) hipGraphDestroy(g); (void) hipGetLastError(); set_err("recording the single-stream graph failed"); return -1; }
+    e->graph = g;
+    if (hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0) != hipSuccess) { (void) hipGetLastError(); set_err("hipGraphInstantiate failed"); return -1; }
+    // (the recording has executed nothing; the counters the pass advanced on the host - launches, the carry's layout - are
+    // the ones a real pass leaves behind, and the batch was not poisoned)
+    b->poisoned = false;
+    return 0;
+}
+
 static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned char *bs_out, int in_bytes)
 {
     HX_IN_OUT x = {in_bytes, 0};
     int nb = 0;
+    hx_batch *b = e->b;
+    // The graph replays a call with exactly the arguments it was recorded with: anything optional (packets, per-frame
+    // counters, debug taps: all set per call by the entry points that need them) goes the plain way, and so do the first
+    // two calls (which load the kernels) and int16 input (the CMp3Enc entry points hand over float).
+    const bool plain = !is_f32 || b->debug || b->pk_buf || b->frame_stats || b->poisoned || b->inflight || e->graph_state < 0 || e->plain_calls < 2;
+    if (!plain && e->graph_state == 0) {
+        const char *env = getenv("HMP3AMD_ENC_GRAPH");
+        e->spin_off = env && atoi(env) == 2;
+        if (env && atoi(env) == 0) e->graph_state = -1;
+        else if (enc_graph_build(e) == 0) e->graph_state = 1;
+        else {      // plain calls from here on (the staging stays allocated until the encoder is re-initialised or destroyed)
+            if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+            e->graph_state = -1;
+        }
+    }
+    if (!plain && e->graph_state == 1) {
+        memcpy(e->h_pcm, pcm, (size_t) 1152 * b->nchan * sizeof(float));
+        const volatile unsigned *seq = &e->h_meta[2];
+        const unsigned before = *seq;
+        bool ok = hipGraphLaunch(e->gexec, e->gq) == hipSuccess;
+        if (ok) {
+            // wait on the graph's last copy in page-locked memory (a few microseconds sooner than the runtime's own wait);
+            // after 2 ms - a descheduled process, a contended device - leave the waiting to the runtime
+            const auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            while (*seq == before) {
+                __builtin_ia32_pause();
+                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+            if (*seq == before || e->spin_off) ok = hipStreamSynchronize(e->gq) == hipSuccess;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (ok) {
+            nb = (int) e->h_meta[0];
+            const int head = nb < HX_ENC_GRAPH_HEAD ? nb : HX_ENC_GRAPH_HEAD;
+            memcpy(bs_out, e->h_out, (size_t) head);
+            if (nb > head) hipMemcpy(bs_out + head, b->d_out + head, (size_t) (nb - head), hipMemcpyDeviceToHost);    // (several frames released at once)
+            x.out_bytes = nb;
+            e->bytes += nb;
+            e->ave = e->ave + ((((nb << 8) - e->ave)) >> (e->p.h_id ? 7 : 6));    // mp3enc.cpp:2328 / :2589
+            e->frames = e->h_meta[1];
+        } else {
+            (void) hipGetLastError();
+            set_err("replaying the single-stream graph failed");
+            b->poisoned = true;
+        }
+        return x;
+    }
     long long stride = (long long) e->outbuf.size();
     if (encode_host(e->b, pcm, is_f32, 1, e->outbuf.data(), stride, &nb) == 0) {
         memcpy(bs_out, e->outbuf.data(), nb);
@@ -1112,6 +1235,7 @@ static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned cha
         e->bytes += nb;
         e->ave = e->ave + ((((nb << 8) - e->ave)) >> (e->p.h_id ? 7 : 6));    // mp3enc.cpp:2328 / :2589
         e->frames = (unsigned) hx_batch_frames_bytes(e->b, 0).a;
+        e->plain_calls++;
     }
     return x;
 }

@@ -176,8 +176,18 @@ __global__ __launch_bounds__(K1_THREADS) void k_polyphase(const int16_t *__restr
 #undef XS
     AnalysisDct<32>::run(b, X, p->dct_tw);
     float *out = sb + ((long long) (s * 2) * SG + (g0 + gl + 3)) * 576 + t;
+#ifdef HX_MOCK_NOSB_STORE
+    // (timing experiment, EXPERIMENTS.md round 6: what the polyphase costs when its output does not go to HBM - the bound of a
+    // polyphase -> MDCT fusion; the condition is false at run time, the compiler cannot know)
+    if (NG > 0x7fff0000)
+#endif
+    {
 #pragma unroll
     for (int k = 0; k < 32; k++) out[18 * k] = X[k].x;
+    }
+#ifdef HX_MOCK_NOSB_STORE
+    if (NG > 0x7fff0000)
+#endif
     if (nchan == 2) {
         float *out1 = out + (long long) SG * 576;
 #pragma unroll
@@ -706,7 +716,12 @@ __device__ __forceinline__ void spec_granule(const float *__restrict__ sb, const
     if constexpr (DIRECT) {
         // every lane takes its subband's 18 + 18 samples straight from global memory (72 contiguous bytes per block, 8-byte
         // aligned; the wave's 64 lanes cover two contiguous 2304-byte runs per channel)
+#ifdef HX_MOCK_NOSB_LOAD
+        // (timing experiment: every workgroup reads the same two blocks - cache hits, no HBM traffic for the subband samples)
+        const float2 *b1 = reinterpret_cast<const float2 *>(sb + (long long) ch * SG * 576 + sbnd * 18);
+#else
         const float2 *b1 = reinterpret_cast<const float2 *>(sb + ((long long) (s * 2 + ch) * SG + g) * 576 + sbnd * 18);
+#endif
         const float2 *b2 = b1 + 288;
 #pragma unroll
         for (int i = 0; i < 9; i++) { const float2 a = b1[i], b = b2[i]; g1[2 * i] = a.x; g1[2 * i + 1] = a.y; g2[2 * i] = b.x; g2[2 * i + 1] = b.y; }

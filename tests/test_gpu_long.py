@@ -39,3 +39,14 @@ def test_hf_slice_on_the_low_footprint_build():
 def test_strict_band_sums_everywhere():
     """every certified band sum replaced by the strict line-order sum (HMP3AMD_EXACT_SUMS=1): same bytes as the oracle"""
     _fuzz(["400", "6004"], {"HMP3AMD_K6": "slim", "HMP3AMD_EXACT_SUMS": "1"})
+
+
+def test_bench_line_with_every_stream_verified():
+    """bench.py --verify all: the timed config-2 batch's 1024 streams, all of them, re-encoded by the oracle over all steps"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--verify", "all", "--no-cpu-baseline", "--no-worst-case",
+                        "--host-fed", "0", "--other-configs", "0"], capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["verify"]["checked"] == 1024 and d["verify"]["identical"] == 1024 and d["kernel_status"] == 0
+    assert d["stream_ms"]["streams"] == 1024 and d["stream_ms"]["max"] >= d["stream_ms"]["p99"] >= d["stream_ms"]["mean"] > 0

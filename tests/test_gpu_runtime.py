@@ -118,6 +118,36 @@ def test_bench_two_ranks_encode_disjoint_stream_blocks():
     assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
 
 
+@pytest.mark.one_k6_build
+def test_eight_rank_preflight_on_one_gpu():
+    """Everything of the first real 8-GPU run except the devices (the driver has not had an 8-GPU node yet): eight
+    processes started by bench.py itself, rendezvous on 127.0.0.1, NUMA binding, page-locked buffers and the host-fed passes,
+    per-rank verification against the oracle, the shares of configs 4 and 5 (the configs BASELINE defines on 8 GPUs) with
+    stream classes / correlations cycling across the rank boundaries, the strong-scaling split of config 2's 1024 streams
+    (128 per rank), the max-over-ranks clock, exit codes - on one GPU (--share-gpu) over gloo, at 128 streams x 32 frames per rank."""
+    import time
+    t0 = time.time()
+    rc, line, err = _bench(["--gpus", "8", "--share-gpu", "--backend", "gloo", "--streams", "128", "--frames", "32", "--steps", "2", "--warmup", "1",
+                            "--verify", "16", "--no-cpu-baseline", "--no-worst-case", "--other-size", "128,32", "--strong-scaling", "1"], timeout=600)
+    wall = time.time() - t0
+    assert rc == 0, (line, err[-2000:])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["ranks_failed"] == [] and line["kernel_status"] == 0
+    assert line["verify"]["checked"] == 16 and line["verify"]["identical"] == 16          # two streams of every rank's own block
+    pl = line["host_placement"]
+    assert len(pl) == 8 and sorted(p["rank"] for p in pl) == list(range(8)) and all(p["device"] == 0 for p in pl)
+    assert all("host_fed_ms_per_step" in p and set(p.get("host_fed_ms_per_step_other", {})) == {"4", "5"} for p in pl), pl
+    oc = {o["baseline_config"]: o for o in line["other_configs"]}
+    assert set(oc) == {4, 5}
+    for c in (4, 5):
+        assert oc[c]["kernel_status"] == 0 and oc[c]["verified_streams"] == oc[c]["verify_checked"] == 16, oc[c]
+        assert oc[c]["host_fed"]["kernel_status"] == 0 and oc[c]["host_fed"]["value"] > 0
+    ss = line["strong_scaling"]
+    assert ss["streams_total"] == 1024 and ss["streams_this_rank"] == 128 and ss["kernel_status_rank0"] == 0 and ss["value"] > 0
+    assert line["host_fed"]["kernel_status"] == 0 and len(line["roofline"]["kernel_ms_per_rank"]) == 8
+    assert wall < 240, "the pre-flight took %.0f s" % wall
+    print("eight-rank pre-flight: %.0f s" % wall)
+
+
 def test_bench_line_shows_a_failing_rank_and_exits_non_zero():
     """a failure on a rank other than 0 must not be invisible: the line names the rank, the exit code is non-zero"""
     rc, line, err = _bench(["--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "8", "--frames", "4", "--steps", "1", "--warmup", "1",
