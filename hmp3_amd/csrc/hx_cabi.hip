@@ -70,6 +70,7 @@ static void set_err(const char *fmt, const char *a = "")
         hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_err("launch of " #kernel " failed: %s", hipGetErrorString(e_)); return -1; } } while (0)
 #define LAUNCH(kernel, grid, block, stream, ...) LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)
 
+#define HX_PARK_MAX 64
 struct hx_batch {
     int device = 0, S = 0, maxF = 0, ncls = 0;
     std::vector<HxParams> params;       // host copy per class
@@ -156,6 +157,9 @@ struct hx_batch {
     // (Round 4: config 2 +1.0 %, its worst-case signal set +2.1 %.)
     int lpt = 2;
     int ncu = 256;                      // compute units of the device
+    int park_k = 8;                     // HMP3AMD_PARK: the CUs of this many longest streams are kept free of other kernels' workgroups (0 = off; see hx_alloc3.inc, "parking")
+    int park_pair = 0;                  // HMP3AMD_PARK_PAIR=1: also the CU that shares the instruction cache with a straggler's
+    int front_chunk = 0;                // HMP3AMD_FRONT_CHUNK: streams per pass of the front-end chain (0 = the whole batch at once)
     int strict_sums = 0;                // HMP3AMD_EXACT_SUMS=1: the stream walk adds every band in line order instead of certifying a parallel sum (tests)
 };
 
@@ -292,12 +296,15 @@ extern "C" hx_batch *hx_batch_create(int device, int nstreams, const HX_E_CONTRO
     ALLOC(b->d_outbytes, sizeof(int) * S);
     if (const char *e = getenv("HMP3AMD_LPT")) b->lpt = atoi(e);
     if (const char *e = getenv("HMP3AMD_EXACT_SUMS")) b->strict_sums = atoi(e) != 0;
+    if (const char *e = getenv("HMP3AMD_FRONT_CHUNK")) b->front_chunk = atoi(e);
+    if (const char *e = getenv("HMP3AMD_PARK_PAIR")) b->park_pair = atoi(e) != 0;
+    if (const char *e = getenv("HMP3AMD_PARK")) { b->park_k = atoi(e); if (b->park_k < 0) b->park_k = 0; if (b->park_k > HX_PARK_MAX) b->park_k = HX_PARK_MAX; }
     ALLOC(b->d_lens, sizeof(int) * 4 * S);
-    ALLOC(b->d_dur, sizeof(unsigned) * S);
+    ALLOC(b->d_dur, sizeof(unsigned) * 2 * S);        // [S] durations, [S] where workgroup i of the last launch ran (see "place")
     ALLOC(b->d_order, sizeof(int) * S);
-    HIPCHKN(hipMemset(b->d_dur, 0, sizeof(unsigned) * S));
-    ALLOC(b->d_done, 8 * sizeof(int));
-    HIPCHKN(hipMemset(b->d_done, 0, 8 * sizeof(int)));
+    HIPCHKN(hipMemset(b->d_dur, 0, sizeof(unsigned) * 2 * S));
+    ALLOC(b->d_done, (8 + HX_PARK_MAX) * sizeof(int));       // ([8 ..]: CU ids of the parking scheme, hx_alloc3.inc)
+    HIPCHKN(hipMemset(b->d_done, 0, (8 + HX_PARK_MAX) * sizeof(int)));
     {
         hipDeviceProp_t prop;
         int per_cu = 0;
@@ -599,25 +606,42 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     const float *pcmf = b->any_dc ? b->d_pcmf : d_pcm32;       // fp32 samples the polyphase reads, or null for int16
     if (b->any_dc) LAUNCH(k_dcfilter, dim3((b->nchan * S + 63) / 64), dim3(64), q, d_pcm, d_pcm32, nsamp, b->d_st, b->d_prm, b->d_pcmf, S, b->nchan);
     // (the carry in slots 0..2 is not written by k_polyphase, so the two may run in either order)
-    int tot = S * 2 * 9;
-    LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q, b->d_sb, b->d_gt, b->d_eng, NG, SG, tot, b->lsf);
-    LAUNCH(k_polyphase, g1, dim3(K1_THREADS), q, d_pcm, nsamp, b->d_st, b->d_prm, b->d_gt, b->d_sb, NG, SG, pcmf, b->nchan, b->d_eng, b->lsf);
-    tot = S * NG;
-    LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, b->d_st, b->d_prm, b->d_eng, b->d_flg,
-           b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
-    LAUNCH(k_blocktype, dim3((S + 63) / 64), dim3(64), q, b->d_st, b->d_flg, b->d_eng, x_bt, x_btprev, NG, S);
-    // (the form of K4 that goes with the stream-walk kernel: hx_front.hip, spec_granule)
-    if (b->slim) LAUNCH(k_spec_direct, dim3((unsigned) ((long long) S * nframes)), dim3(128), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
-                        x_etab, x_thr, x_msbase, NG, SG);
-    else LAUNCH(k_spec, dim3((unsigned) ((long long) S * nframes)), dim3(128), q, b->d_sb, b->d_st, b->d_prm, b->d_gt, x_bt, x_xr,
-                x_etab, x_thr, x_msbase, NG, SG);
-    // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
-    // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
-    LAUNCH(k_msscan, dim3(S), dim3(64), q, b->d_st, b->d_prm, x_msbase, x_bt, x_msflag, x_msdec, x_thr, x_thrprev, NG, b->lsf);
-    LAUNCH(k_prep, dim3((unsigned) (((long long) S * NG + 3) / 4)), dim3(256), q, (const float *) x_xr, (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, b->debug ? x_x34 : (float *) nullptr, x_sgn, x_band, b->d_st, b->d_prm, b->d_gt, x_bt, x_msflag,
-           x_etab, x_thr, x_thrprev, NG, (long long) S * NG);
-    // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
-    LAUNCH(k_carry, dim3(S * 2), dim3(256), q, b->d_sb, b->d_st, d_pcm, nsamp, NG, SG, S, pcmf, b->nchan);
+    // The chain runs over the whole batch, or (b->front_chunk, HMP3AMD_FRONT_CHUNK) over blocks of streams one after the
+    // other: a block's subband samples and spectrum (2.4 + 1.2 MB per stream at 256 frames) are then still in the memory-side
+    // cache when the next kernel of the chain reads them.  Every kernel indexes its per-stream arrays from the block's first stream.
+    const int C = (b->front_chunk > 0 && b->front_chunk < S && !b->debug) ? b->front_chunk : S;
+    auto front = [&](int s0, int Sc) -> int {
+        const long long o = s0;
+        float *sb_c = b->d_sb + o * 2 * SG * 576;
+        int *eng_c = b->d_eng + o * 2 * NG * 9;
+        HxStream *st_c = b->d_st + o;
+        const int16_t *pcm_c = d_pcm ? d_pcm + o * nsamp * b->nchan : nullptr;
+        const float *pcmf_c = pcmf ? pcmf + o * nsamp * b->nchan : nullptr;
+        unsigned char *bt_c = x_bt + o * NG;
+        dim3 g1c(Sc, (NG + K1_GPB - 1) / K1_GPB);
+        int tot = Sc * 2 * 9;
+        LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q, sb_c, b->d_gt, eng_c, NG, SG, tot, b->lsf);
+        LAUNCH(k_polyphase, g1c, dim3(K1_THREADS), q, pcm_c, nsamp, st_c, b->d_prm, b->d_gt, sb_c, NG, SG, pcmf_c, b->nchan, eng_c, b->lsf);
+        tot = Sc * NG;
+        LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, st_c, b->d_prm, eng_c, b->d_flg + o * NG,
+               b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
+        LAUNCH(k_blocktype, dim3((Sc + 63) / 64), dim3(64), q, st_c, b->d_flg + o * NG, eng_c, bt_c, x_btprev + o, NG, Sc);
+        // (the form of K4 that goes with the stream-walk kernel: hx_front.hip, spec_granule)
+        if (b->slim) LAUNCH(k_spec_direct, dim3((unsigned) ((long long) Sc * nframes)), dim3(128), q, sb_c, st_c, b->d_prm, b->d_gt, bt_c, x_xr + o * NG * 1152,
+                            x_etab + o * NG * 128, x_thr + o * NG * 128, x_msbase + o * NG, NG, SG);
+        else LAUNCH(k_spec, dim3((unsigned) ((long long) Sc * nframes)), dim3(128), q, sb_c, st_c, b->d_prm, b->d_gt, bt_c, x_xr + o * NG * 1152,
+                    x_etab + o * NG * 128, x_thr + o * NG * 128, x_msbase + o * NG, NG, SG);
+        // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
+        // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
+        LAUNCH(k_msscan, dim3(Sc), dim3(64), q, st_c, b->d_prm, x_msbase + o * NG, bt_c, x_msflag + o * NG, x_msdec + o * NG, x_thr + o * NG * 128, x_thrprev + o * 128, NG, b->lsf);
+        LAUNCH(k_prep, dim3((unsigned) (((long long) Sc * NG + 3) / 4)), dim3(256), q, (const float *) (x_xr + o * NG * 1152), (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, b->debug ? x_x34 : (float *) nullptr,
+               x_sgn + o * NG * 2 * HX_SGN_WORDS, x_band + o * NG, st_c, b->d_prm, b->d_gt, bt_c, x_msflag + o * NG,
+               x_etab + o * NG * 128, x_thr + o * NG * 128, x_thrprev + o * 128, NG, (long long) Sc * NG);
+        // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
+        LAUNCH(k_carry, dim3(Sc * 2), dim3(256), q, sb_c, st_c, pcm_c, nsamp, NG, SG, Sc, pcmf_c, b->nchan);
+        return 0;
+    };
+    for (int s0 = 0; s0 < S; s0 += C) if (front(s0, (S - s0 < C) ? S - s0 : C) != 0) return -1;
     if (pipelined) {
         HIPCHK(hipEventRecord(b->ev_front[set], q));
         HIPCHK(hipStreamWaitEvent(qa, b->ev_front[set], 0));
@@ -645,9 +669,13 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     a.strict_sums = b->strict_sums;
     a.dur = b->d_dur;
     a.order = nullptr;
+    a.park_k = 0;
     if ((S > b->resident && b->lpt) || (b->lpt == 2 && S > b->ncu) || b->lpt == 3) {       // longest first (see hx_batch::lpt)
         LAUNCH(k_order, dim3(1), dim3(1024), qa, (const unsigned *) b->d_dur, b->d_order, S);
         a.order = b->d_order;
+        // parking (hx_alloc3.inc): only when every stream has a slot from the launch's start - beyond the resident set a
+        // parked slot would keep a waiting stream out - and from the second call on (the order is the previous call's)
+        if (S <= b->resident && b->alloc_launches > 0 && !b->alloc1 && !b->lsf) a.park_k = (b->park_k < S / 8 ? b->park_k : S / 8) | (b->park_pair << 16);
     }
     a.x34 = x_x34; a.sgn = x_sgn; a.band = x_band; a.msflag = x_msflag; a.msdec = x_msdec; a.thrprev = x_thrprev;
     a.ixq = x_ixq; a.sgn_w = x_sgn; a.seg = x_seg; a.frm = x_frm; a.slots = x_slots;
@@ -993,6 +1021,7 @@ extern "C" long long hx_batch_debug_read(hx_batch *b, const char *name, void *ds
     else if (k == "etab") { src = b->d_etab; n = sizeof(float) * S * NG * 128; }
     else if (k == "thr") { src = b->d_thr; n = sizeof(float) * S * NG * 128; }
     else if (k == "msbase") { src = b->d_msbase; n = sizeof(int) * S * NG; }
+    else if (k == "place") { src = b->d_dur + S; n = sizeof(unsigned) * S; }       // per WORKGROUP of the last allocator launch (launch order): XCC id << 16 | HW_ID[15:0] (CU [11:8], SH [12], SE [15:13])
     else if (k == "dur") { src = b->d_dur; n = sizeof(unsigned) * S; }              // the last allocator launch's per-stream durations, 100 MHz ticks
     else if (k == "big_sweeps") { src = b->d_done + 3; n = sizeof(int); }        // gain-search line passes that took the double x^(4/3) table
     else if (k == "strict_sums") { src = b->d_done + 4; n = sizeof(int); }       // certified band sums that fell back to the strict line-order sum

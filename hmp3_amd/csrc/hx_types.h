@@ -226,6 +226,8 @@ struct AllocArgs {
     const int *order;           // workgroup -> stream (longest-running first, from the previous call's durations), or null = identity
     unsigned *dur;              // [S] this call's duration of each stream's workgroup, 100 MHz ticks
     int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter), [3] double-table line passes, [4] certified band sums that fell back to the strict sum
+    int park_k;                 // > 0: the workgroups that share a CU with one of the first park_k workgroups of the launch order (the streams that ran
+                                // longest in the previous call) keep their slot until that one retires (hx_alloc3.inc, "parking"); done_counter[8 ..] holds the CU ids
     int strict_sums;            // 1 = no certified band sums: every band is added in line order (HMP3AMD_EXACT_SUMS=1; tests)
     // from k_msscan / k_prep (hx_front.hip); xr holds the coded magnitudes for long-block granules
     const float *x34;           // [S][NG][2][576] x^(3/4) of the magnitudes (long-block granules)
