@@ -204,6 +204,7 @@ struct alignas(16) AllocLds {
     const double *pow43;                // HxGlobalTabs::pow43 (global memory)
     int *big_counter;                   // device counter of line passes that took the double table (tests)
     int nstrict;                        // certified band sums of this stream that fell back to the strict sum (added to big_counter[1] when the stream retires)
+    int cur_s;                          // the stream this workgroup is walking (the helper wave reads it with a fetch order)
     alignas(16) int cmdw[4];            // work order for the helper wave (see HELPER_POST): command + three arguments, one 16-byte read
     alignas(4) unsigned char gflag[HX_SLIM ? 64 : 256];     // block type | stereo decision << 2 of the next granules (frame loop, hx_alloc3.inc)
 #ifdef HX_PROFILE
@@ -317,7 +318,7 @@ __device__ __forceinline__ int hx_lane_opaque()
 // of the other wave's data moved above it by the compiler (the s_barrier builtin alone does not
 // order memory accesses).
 #define WG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_FETCH, HCMD_QUANT_COUNT };
+enum { HCMD_EXIT = 0, HCMD_COUNT_BITS, HCMD_QUANT, HCMD_ISF2, HCMD_LUCKY, HCMD_SEEK, HCMD_FETCH, HCMD_QUANT_COUNT, HCMD_SYNC /* nothing: the helper is through with what went before */ };
 #define HELPER_POST(c_, a0_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); } \
         WG_BARRIER(); } while (0)
 #define HELPER_POST2(c_, a0_, a1_) do { if (LANE == 0) { L.cmdw[0] = (c_); L.cmdw[1] = (a0_); L.cmdw[2] = (a1_); } \

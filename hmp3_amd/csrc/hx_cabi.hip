@@ -46,6 +46,7 @@ __global__ void k_alloc1(AllocArgs a);
 __global__ void k_alloc1_lsf(AllocArgs a);
 extern "C" int k_alloc_lds_bytes();
 extern "C" int k_alloc_slim_lds_bytes();
+extern "C" int k_alloc_slim_persistent();      // 1: the kernel's workgroups claim streams from a counter (hx_alloc3.inc, HX_PERSIST)
 extern "C" int k_alloc_lsf_lds_bytes();
 extern "C" int k_alloc1_lds_bytes();
 extern "C" int k_alloc1_lsf_lds_bytes();
@@ -687,10 +688,14 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, qa));
     }
-    if (b->alloc1) { if (b->lsf) LAUNCH_LDS(k_alloc1_lsf, dim3(S), dim3(128), K6_LDS(k_alloc1_lsf), qa, a); else LAUNCH_LDS(k_alloc1, dim3(S), dim3(128), K6_LDS(k_alloc1), qa, a); }
-    else if (b->lsf) LAUNCH_LDS(k_alloc_lsf, dim3(S), dim3(128), K6_LDS(k_alloc_lsf), qa, a);
-    else if (b->slim) LAUNCH_LDS(k_alloc_slim, dim3(S), dim3(128), K6_LDS(k_alloc_slim), qa, a);
-    else LAUNCH_LDS(k_alloc, dim3(S), dim3(128), K6_LDS(k_alloc), qa, a);
+    // persistent workgroups: as many as the chip holds at once (or one per stream if that is fewer); each walks one stream of
+    // the launch order after the other (hx_alloc3.inc)
+    // (built into k_alloc_slim, the kernel of batches beyond the resident set; the 256-register kernels keep one workgroup per stream)
+    const int G = (b->slim && !b->alloc1 && !b->lsf && k_alloc_slim_persistent() && S > b->resident) ? b->resident : S;
+    if (b->alloc1) { if (b->lsf) LAUNCH_LDS(k_alloc1_lsf, dim3(G), dim3(128), K6_LDS(k_alloc1_lsf), qa, a); else LAUNCH_LDS(k_alloc1, dim3(G), dim3(128), K6_LDS(k_alloc1), qa, a); }
+    else if (b->lsf) LAUNCH_LDS(k_alloc_lsf, dim3(G), dim3(128), K6_LDS(k_alloc_lsf), qa, a);
+    else if (b->slim) LAUNCH_LDS(k_alloc_slim, dim3(G), dim3(128), K6_LDS(k_alloc_slim), qa, a);
+    else LAUNCH_LDS(k_alloc, dim3(G), dim3(128), K6_LDS(k_alloc), qa, a);
     if (!b->capturing) {
         HIPCHK(hipEventRecord(e1, qa));
         b->pending.push_back({e0, e1});

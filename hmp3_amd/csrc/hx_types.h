@@ -225,7 +225,8 @@ struct AllocArgs {
     int *pre_len, *carry_len;   // [S] bytes of pending frames' images at the call's start (k_pack_pre copies them in) / at its end (k_pack_carry saves them)
     const int *order;           // workgroup -> stream (longest-running first, from the previous call's durations), or null = identity
     unsigned *dur;              // [S] this call's duration of each stream's workgroup, 100 MHz ticks
-    int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter), [3] double-table line passes, [4] certified band sums that fell back to the strict sum
+    int *done_counter;          // [0] streams retired, [2] streams started by all launches so far (k_gate of a pipelined submit waits on the latter), [3] double-table line passes, [4] certified band sums that fell back to the strict sum,
+                                // [5] positions of the launch order claimed so far in this launch, [6] workgroups of this launch that ran out of work (the last one zeroes both), [8 ..] parking
     int park_k;                 // > 0: the workgroups that share a CU with one of the first park_k workgroups of the launch order (the streams that ran
                                 // longest in the previous call) keep their slot until that one retires (hx_alloc3.inc, "parking"); done_counter[8 ..] holds the CU ids
     int strict_sums;            // 1 = no certified band sums: every band is added in line order (HMP3AMD_EXACT_SUMS=1; tests)
