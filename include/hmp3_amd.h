@@ -53,7 +53,11 @@ hx_enc *hx_enc_create(int device);                          /* CMp3Enc::CMp3Enc,
 void hx_enc_destroy(hx_enc *e);                             /* CMp3Enc::~CMp3Enc, mp3enc.cpp:201 */
 /* CMp3Enc::L3_audio_encode_init (mp3enc.cpp:220): returns bytes of float PCM per call (9216) or 0 */
 int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec);
-/* CMp3Enc::L3_audio_encode (mp3enc.cpp:2031): 1152 x 2 floats at int16 scale, oldest first */
+/* CMp3Enc::L3_audio_encode (mp3enc.cpp:2031): 1152 x 2 floats at int16 scale, oldest first.
+   From the third call on a call is one HIP-graph launch: the encoder's single-stream chain (PCM up from page-locked staging,
+   the pipeline's kernels, byte count / frame counter / bitstream down) is recorded once and replayed; the bytes per call are
+   those of the plain calls.  The *_Packet calls take the plain path; the environment variable HMP3AMD_ENC_GRAPH=0 restores it
+   for every call (2: replay, but wait with hipStreamSynchronize instead of polling the graph's last copy). */
 HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out);
 /* CMp3Enc::MP3_audio_encode_init (mp3enc.cpp:2655): 8/16/24/32-bit PCM or 32-bit float source at
    8 - 48 kHz, converted to the encode rate by the built-in converter; returns min input bytes per call or 0 */
@@ -231,7 +235,8 @@ int hx_multi_status(hx_multi *m);
 
 /* ---- test taps (tests only; synchronise) ---- */
 /* name: "sb" "xr" "etab" "thr" "msbase" "bt" "eng" "dbg" (per-stage buffers), "ixq" "sgn" "seg" "frm" (what the allocator hands the
-   packer), "dur" (per-stream duration of the last allocator launch, 100 MHz ticks), "state", and two device counters (one int
+   packer), "dur" (per-stream duration of the last allocator launch, 100 MHz ticks), "place" (where position i of that launch's
+   order ran: XCC id << 16 | HW_ID[15:0], i.e. CU [11:8], SH [12], SE [15:13]), "state", and two device counters (one int
    each, running over the batch's calls): "big_sweeps" = noise passes that took the double-precision x^(4/3) table,
    "strict_sums" = certified band sums that fell back to the reference's strict line-order sum (DESIGN.md section 2;
    HMP3AMD_EXACT_SUMS=1 sends every sum there).  Copies at most cap bytes, returns bytes, -1 for an unknown name. */
