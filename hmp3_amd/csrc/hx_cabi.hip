@@ -35,7 +35,7 @@ __global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned *
 __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
                        int frames_per_stream, int NG, int lsf, long long nframes_total);
-__global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes, const int *carry_len);
+__global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes, const int *carry_len, unsigned *frames_out);
 __global__ void k_pack_pre(const HxStream *st, unsigned char *out, long long out_stride, const int *pre_len);
 __global__ void k_order(const unsigned *dur, int *order, int S);
 __global__ void k_gate(const unsigned *done_counter, unsigned base, unsigned need, int *timeouts);
@@ -147,6 +147,9 @@ struct hx_batch {
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
     bool capturing = false;             // the pass is being recorded into a HIP graph (hx_enc_*): no timing events, nothing that queries the stream
+    hipStream_t cap_side = nullptr;     // while recording: a second stream for the chain's independent kernels (k_attack_eng beside k_polyphase, k_carry beside
+    hipEvent_t cap_ev[4] = {nullptr, nullptr, nullptr, nullptr};    // everything behind k_spec): forked and joined with these events = parallel branches of the graph
+    unsigned *cap_frames = nullptr;     // one-stream encoder: where k_pack_carry leaves the stream's frame counter (next to the byte count)
     bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
     // longest-first workgroup order: 2 = for every batch with more streams than the chip has CUs (default: below that no two
     // streams share a CU and the order decides nothing), 3 = always (tests), 1 = only for batches beyond the resident set,
@@ -514,7 +517,7 @@ static int enqueue_pack(hx_batch *b, unsigned char *d_out, long long out_stride,
     LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
            (const short *) x_ixq, (const unsigned *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
            d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total);
-    LAUNCH(k_pack_carry, dim3(S), dim3(64), qp, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes, (const int *) x_carrylen);
+    LAUNCH(k_pack_carry, dim3(S), dim3(64), qp, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes, (const int *) x_carrylen, b->cap_frames);
     return 0;
 }
 
@@ -621,8 +624,13 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         unsigned char *bt_c = x_bt + o * NG;
         dim3 g1c(Sc, (NG + K1_GPB - 1) / K1_GPB);
         int tot = Sc * 2 * 9;
-        LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q, sb_c, b->d_gt, eng_c, NG, SG, tot, b->lsf);
+        const bool fork = b->capturing && b->cap_side;      // (recording a graph: independent kernels on a branch of their own)
+        hipStream_t q2 = fork ? b->cap_side : q;
+        if (fork) { HIPCHK(hipEventRecord(b->cap_ev[0], q)); HIPCHK(hipStreamWaitEvent(q2, b->cap_ev[0], 0)); }
+        LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q2, sb_c, b->d_gt, eng_c, NG, SG, tot, b->lsf);
+        if (fork) HIPCHK(hipEventRecord(b->cap_ev[1], q2));
         LAUNCH(k_polyphase, g1c, dim3(K1_THREADS), q, pcm_c, nsamp, st_c, b->d_prm, b->d_gt, sb_c, NG, SG, pcmf_c, b->nchan, eng_c, b->lsf);
+        if (fork) HIPCHK(hipStreamWaitEvent(q, b->cap_ev[1], 0));
         tot = Sc * NG;
         LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, st_c, b->d_prm, eng_c, b->d_flg + o * NG,
                b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
@@ -632,14 +640,17 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
                             x_etab + o * NG * 128, x_thr + o * NG * 128, x_msbase + o * NG, NG, SG);
         else LAUNCH(k_spec, dim3((unsigned) ((long long) Sc * nframes)), dim3(128), q, sb_c, st_c, b->d_prm, b->d_gt, bt_c, x_xr + o * NG * 1152,
                     x_etab + o * NG * 128, x_thr + o * NG * 128, x_msbase + o * NG, NG, SG);
+        if (fork) { HIPCHK(hipEventRecord(b->cap_ev[2], q)); HIPCHK(hipStreamWaitEvent(q2, b->cap_ev[2], 0)); }
         // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
         // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
         LAUNCH(k_msscan, dim3(Sc), dim3(64), q, st_c, b->d_prm, x_msbase + o * NG, bt_c, x_msflag + o * NG, x_msdec + o * NG, x_thr + o * NG * 128, x_thrprev + o * 128, NG, b->lsf);
         LAUNCH(k_prep, dim3((unsigned) (((long long) Sc * NG + 3) / 4)), dim3(256), q, (const float *) (x_xr + o * NG * 1152), (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, b->debug ? x_x34 : (float *) nullptr,
                x_sgn + o * NG * 2 * HX_SGN_WORDS, x_band + o * NG, st_c, b->d_prm, b->d_gt, bt_c, x_msflag + o * NG,
                x_etab + o * NG * 128, x_thr + o * NG * 128, x_thrprev + o * 128, NG, (long long) Sc * NG);
-        // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them)
-        LAUNCH(k_carry, dim3(Sc * 2), dim3(256), q, sb_c, st_c, pcm_c, nsamp, NG, SG, Sc, pcmf_c, b->nchan);
+        // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them): behind
+        // k_spec, the last reader of the carried slots, and beside everything that follows (joined at the end of the pass)
+        LAUNCH(k_carry, dim3(Sc * 2), dim3(256), q2, sb_c, st_c, pcm_c, nsamp, NG, SG, Sc, pcmf_c, b->nchan);
+        if (fork) HIPCHK(hipEventRecord(b->cap_ev[3], q2));
         return 0;
     };
     for (int s0 = 0; s0 < S; s0 += C) if (front(s0, (S - s0 < C) ? S - s0 : C) != 0) return -1;
@@ -731,6 +742,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         b->nsubmit++;
         b->inflight = true;
     }
+    if (b->capturing && b->cap_side) HIPCHK(hipStreamWaitEvent(qa, b->cap_ev[3], 0));      // the side branch joins the recorded stream
     HIPCHK(hipGetLastError());
     b->lastNG = NG;
     return 0;
@@ -1112,23 +1124,29 @@ struct hx_enc {
     // One call = one graph launch: the whole single-stream chain (PCM up, the pipeline's kernels, byte count / frame counter /
     // bitstream down) is recorded once into a HIP graph over page-locked staging buffers and replayed per call
     // (reference call being replaced: CMp3Enc::L3_audio_encode, mp3enc.cpp:2031-2073, and MP3_audio_encode, :2812-2866).
-    hipStream_t gq = nullptr;
+    hipStream_t gq = nullptr, gq2 = nullptr;
+    hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned char *d_encbuf = nullptr;  // device: [byte count | frame counter | ... HX_ENC_GRAPH_OFF | the call's bitstream]
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     float *h_pcm = nullptr;             // page-locked: one 1152-sample block, float at int16 scale
-    unsigned char *h_out = nullptr;     // page-locked: the head of the call's output (HX_ENC_GRAPH_HEAD bytes; the rest is fetched when a call emits more)
-    unsigned *h_meta = nullptr;         // page-locked: [0] bytes emitted by the call, [1] the stream's frame counter, [2] allocator launches so far (the graph's last copy: changes with every replay)
+    unsigned char *h_out = nullptr;     // page-locked: image of the head of d_encbuf (HX_ENC_GRAPH_HEAD bytes of bitstream; the rest is fetched when a call emits more)
+    unsigned *h_meta = nullptr;         // page-locked: [2] allocator launches so far (the graph's last copy: changes with every replay)
     int graph_state = 0;                // 0 = not built yet, 1 = ready, -1 = not available (disabled, or the build failed: plain calls)
     bool spin_off = false;              // HMP3AMD_ENC_GRAPH=2: always wait with hipStreamSynchronize (A/B of the wait)
     int plain_calls = 0;                // calls made the plain way since init (the first ones: they also load the kernels' code objects)
 };
 #define HX_ENC_GRAPH_HEAD 8192
+#define HX_ENC_GRAPH_OFF 256
 
 static void enc_graph_drop(hx_enc *e)
 {
     if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
     if (e->gq) { hipStreamDestroy(e->gq); e->gq = nullptr; }
+    if (e->gq2) { hipStreamDestroy(e->gq2); e->gq2 = nullptr; }
+    for (int i = 0; i < 4; i++) if (e->gev[i]) { hipEventDestroy(e->gev[i]); e->gev[i] = nullptr; }
+    if (e->d_encbuf) { hipFree(e->d_encbuf); e->d_encbuf = nullptr; }
     if (e->h_pcm) { hipHostFree(e->h_pcm); e->h_pcm = nullptr; }
     if (e->h_out) { hipHostFree(e->h_out); e->h_out = nullptr; }
     if (e->h_meta) { hipHostFree(e->h_meta); e->h_meta = nullptr; }
@@ -1170,32 +1188,43 @@ extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
 }
 
 // Record the single-stream chain of e->b into a graph (see hx_enc).  Returns 0 when e->gexec is ready.
+// Device side: one buffer [byte count | frame counter | ... 256 | bitstream], so that the call's results come down in one copy;
+// the graph's last node copies the allocator-launch counter, which the call polls.  The chain's independent kernels
+// (k_attack_eng beside k_polyphase, k_carry beside everything behind k_spec) are recorded on a second stream: parallel branches.
 static int enc_graph_build(hx_enc *e)
 {
     hx_batch *b = e->b;
     HIPCHK(hipSetDevice(b->device));
     const long long stride = (long long) e->outbuf.size();
-    const long long pbytes = 1152LL * b->nchan * (long long) sizeof(float), obytes = stride;
-    // the staging the host-buffer calls use, allocated before the capture starts (no allocation inside one)
+    const long long pbytes = 1152LL * b->nchan * (long long) sizeof(float);
+    // allocated before the recording starts (no allocation inside one)
     if (pbytes > b->pcm_cap) { if (b->d_pcm) hipFree(b->d_pcm); HIPCHK(hipMalloc((void **) &b->d_pcm, pbytes)); b->pcm_cap = pbytes; }
-    if (obytes > b->out_cap) { if (b->d_out) hipFree(b->d_out); HIPCHK(hipMalloc((void **) &b->d_out, obytes)); b->out_cap = obytes; }
+    HIPCHK(hipMalloc((void **) &e->d_encbuf, (size_t) (HX_ENC_GRAPH_OFF + stride)));
+    HIPCHK(hipMemset(e->d_encbuf, 0, (size_t) (HX_ENC_GRAPH_OFF + stride)));
     HIPCHK(hipHostMalloc((void **) &e->h_pcm, (size_t) pbytes, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **) &e->h_out, HX_ENC_GRAPH_HEAD, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &e->h_out, HX_ENC_GRAPH_OFF + HX_ENC_GRAPH_HEAD, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **) &e->h_meta, 4 * sizeof(unsigned), hipHostMallocDefault));
-    e->h_meta[0] = e->h_meta[1] = 0;
     HIPCHK(hipMemcpy(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
     HIPCHK(hipStreamCreateWithFlags(&e->gq, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->gq2, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&e->gev[i], hipEventDisableTiming));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipStreamBeginCapture(e->gq, hipStreamCaptureModeThreadLocal));
     int r = 0;
     b->capturing = true;
+    // (HMP3AMD_ENC_GRAPH_FORK=1: the independent kernels as parallel branches - measured slower, 130 against 104 us per call:
+    // a branch costs more in cross-queue synchronisation than the two short kernels it takes off the chain)
+    const char *fk = getenv("HMP3AMD_ENC_GRAPH_FORK");
+    b->cap_side = (fk && atoi(fk) != 0) ? e->gq2 : nullptr;
+    for (int i = 0; i < 4; i++) b->cap_ev[i] = e->gev[i];
+    b->cap_frames = reinterpret_cast<unsigned *>(e->d_encbuf) + 1;
     if (hipMemcpyAsync(b->d_pcm, e->h_pcm, (size_t) pbytes, hipMemcpyHostToDevice, e->gq) != hipSuccess) r = -1;
-    if (!r) r = encode_core(b, nullptr, (const float *) b->d_pcm, 1, b->d_out, stride, b->d_outbytes, e->gq);
+    if (!r) r = encode_core(b, nullptr, (const float *) b->d_pcm, 1, e->d_encbuf + HX_ENC_GRAPH_OFF, stride, reinterpret_cast<int *>(e->d_encbuf), e->gq);
     b->capturing = false;
-    if (!r && hipMemcpyAsync(&e->h_meta[0], b->d_outbytes, sizeof(int), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
-    if (!r && hipMemcpyAsync(&e->h_meta[1], (char *) b->d_st + offsetof(HxStream, tot_frames_out), sizeof(unsigned), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    b->cap_side = nullptr;
+    b->cap_frames = nullptr;
     const size_t head = (size_t) (stride < HX_ENC_GRAPH_HEAD ? stride : HX_ENC_GRAPH_HEAD);
-    if (!r && hipMemcpyAsync(e->h_out, b->d_out, head, hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    if (!r && hipMemcpyAsync(e->h_out, e->d_encbuf, HX_ENC_GRAPH_OFF + head, hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
     // last node: the count of allocator workgroups started so far (one more per call of a one-stream batch).  The copies of a
     // recorded stream run in order, so when this word changes in host memory the call's other results have landed.
     if (!r && hipMemcpyAsync(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
@@ -1247,14 +1276,14 @@ static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned cha
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (ok) {
-            nb = (int) e->h_meta[0];
+            nb = *reinterpret_cast<const int *>(e->h_out);
             const int head = nb < HX_ENC_GRAPH_HEAD ? nb : HX_ENC_GRAPH_HEAD;
-            memcpy(bs_out, e->h_out, (size_t) head);
-            if (nb > head) hipMemcpy(bs_out + head, b->d_out + head, (size_t) (nb - head), hipMemcpyDeviceToHost);    // (several frames released at once)
+            memcpy(bs_out, e->h_out + HX_ENC_GRAPH_OFF, (size_t) head);
+            if (nb > head) hipMemcpy(bs_out + head, e->d_encbuf + HX_ENC_GRAPH_OFF + head, (size_t) (nb - head), hipMemcpyDeviceToHost);    // (several frames released at once)
             x.out_bytes = nb;
             e->bytes += nb;
             e->ave = e->ave + ((((nb << 8) - e->ave)) >> (e->p.h_id ? 7 : 6));    // mp3enc.cpp:2328 / :2589
-            e->frames = e->h_meta[1];
+            e->frames = reinterpret_cast<const unsigned *>(e->h_out)[1];
         } else {
             (void) hipGetLastError();
             set_err("replaying the single-stream graph failed");

@@ -282,10 +282,12 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
 // and are put at the head of the next call's `out` before its packing (k_pack_pre).  The lengths are per call
 // (written by that call's allocator launch), because the next call's allocator may already have run.
 __global__ __launch_bounds__(64) void k_pack_carry(HxStream *__restrict__ st, const unsigned char *__restrict__ out, long long out_stride,
-                                                   const int *__restrict__ out_bytes, const int *__restrict__ carry_len)
+                                                   const int *__restrict__ out_bytes, const int *__restrict__ carry_len, unsigned *__restrict__ frames_out)
 {
     const int s = blockIdx.x;
     HxStream *ss = st + s;
+    // (the one-stream encoder's graph copies the stream's frame counter down with the call's byte count: one copy instead of two)
+    if (frames_out && threadIdx.x == 0) frames_out[s] = ss->tot_frames_out;
     const unsigned char *src = out + (long long) s * out_stride + out_bytes[s];
     const int n = carry_len[s];
     for (int i = threadIdx.x; i < n; i += 64) ss->main_buf[i] = src[i];
