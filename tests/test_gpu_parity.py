@@ -429,8 +429,70 @@ def test_pipelined_submit_equals_plain_calls_and_oracle():
         got[mode] = [b"".join(outs[c][s, :nbs[c][s]].tobytes() for c in range(calls)) for s in range(S)]
         b.close()
     assert got["submit_gate90"] == got["plain"] and got["submit_gate0"] == got["plain"]
-    for s in range(0, S, 64):
-        assert got["plain"][s] == oracle_bytes(kw, pcm[s], F * calls), "stream %d" % s
+    # (512 streams on 256 CUs: the launch order is the previous call's durations and, from the second call on, the CU-mates
+    # of the eight longest streams park - every stream against the oracle)
+    from oracle_pool import oracle_bytes_many
+    want = oracle_bytes_many(kw, pcm, F * calls)
+    bad = [s for s in range(S) if got["plain"][s] != want[s]]
+    assert not bad, "%d of %d streams differ from the oracle, first: %s" % (len(bad), S, bad[:8])
+
+
+@pytest.mark.one_k6_build
+@pytest.mark.parametrize("park", ["0", "8", "64"])
+def test_parking_changes_no_byte_and_the_placement_tap_names_every_cu(park, monkeypatch):
+    """HMP3AMD_PARK (hx_alloc3.inc, "parking"): the workgroups that share a CU with one of the launch's longest streams keep
+    their slot until that stream retires.  Scheduling only: same bytes as the oracle with it off, at its default and at its
+    maximum; the placement tap ("place") reports (XCC, SE, CU) per position of the launch order - 1024 streams of the
+    four-per-CU kernel land four to a CU on 256 distinct CUs."""
+    import torch
+    monkeypatch.setenv("HMP3AMD_PARK", park)
+    monkeypatch.setenv("HMP3AMD_K6", "fat")
+    kw = dict(bitrate=64, short_block_threshold=99999)
+    S, F, calls = 1024, 6, 3
+    base = [synth.stream_pcm(7100 + u, F * calls, rho=RHOS[u % 4]) for u in range(64)]
+    pcm = np.stack([np.roll(base[i % 64], 1152 * (i // 64), axis=0) for i in range(S)])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    got = [b"" for _ in range(S)]
+    for c in range(calls):
+        out = b.encode_host(pcm[:, c * F * 1152:(c + 1) * F * 1152])
+        for s in range(S):
+            got[s] += out[s]
+    assert b.status() == 0
+    place = b.debug_read("place", np.uint32, S)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    cus, counts = np.unique(place & 0xFFFFFF00, return_counts=True)
+    assert len(cus) == min(ncu, S) and counts.max() <= 4 and len(np.unique(place >> 16)) == 8, (len(cus), counts.max())
+    b.close()
+    from oracle_pool import oracle_bytes_many
+    want = oracle_bytes_many(kw, pcm, F * calls)
+    bad = [s for s in range(S) if got[s] != want[s]]
+    assert not bad, "%d of %d streams differ from the oracle, first: %s" % (len(bad), S, bad[:8])
+
+
+@pytest.mark.one_k6_build
+def test_persistent_workgroups_walk_more_streams_than_slots_over_several_calls(monkeypatch):
+    """Beyond the resident set k_alloc_slim runs as many workgroups as the chip holds and each claims stream after stream of
+    the launch order from a counter (hx_alloc3.inc, HX_PERSIST): 1600 streams on 1536 slots, three calls (the second and third
+    in the order of the previous call's durations), every stream against the oracle; the counter is back at zero after
+    every launch (the next one starts from position 0: all 1600 streams come out)."""
+    monkeypatch.setenv("HMP3AMD_K6", "slim")
+    kw = dict()      # VBR -V50, block switching
+    S, F, calls = 1600, 5, 3
+    base = [synth.stream_pcm(7300 + u, F * calls, rho=RHOS[u % 4], bursts=True) for u in range(50)]
+    pcm = np.stack([np.roll(base[i % 50], 1152 * (i // 50), axis=0) for i in range(S)])
+    b = api().Batch(api().default_control(**kw), nstreams=S, max_frames=F)
+    assert b.k6_variant() == 1 and b.resident_streams() < S
+    got = [b"" for _ in range(S)]
+    for c in range(calls):
+        out = b.encode_host(pcm[:, c * F * 1152:(c + 1) * F * 1152])
+        for s in range(S):
+            got[s] += out[s]
+    assert b.status() == 0
+    b.close()
+    from oracle_pool import oracle_bytes_many
+    want = oracle_bytes_many(kw, pcm, F * calls)
+    bad = [s for s in range(S) if got[s] != want[s]]
+    assert not bad, "%d of %d streams differ from the oracle, first: %s" % (len(bad), S, bad[:8])
 
 
 def test_pipelined_host_calls_equal_plain_host_calls():
