@@ -451,7 +451,9 @@ def main():
             # (device wall clock, 100 MHz ticks -> ms); a launch lasts as long as its slowest stream
             d = batch.debug_read("dur", np.uint32, S).astype(np.float64) / 1e5
             m["stream_ms"] = {"min": round(float(d.min()), 3), "mean": round(float(d.mean()), 3), "p50": round(float(np.percentile(d, 50)), 3),
-                              "p99": round(float(np.percentile(d, 99)), 3), "max": round(float(d.max()), 3), "streams": int(S), "frames": int(F)}
+                              "p99": round(float(np.percentile(d, 99)), 3), "max": round(float(d.max()), 3), "streams": int(S), "frames": int(F),
+                              # the three slowest streams (index in this rank's block, ms): at a resident-set batch the launch IS the first of them
+                              "slowest": [[int(i), round(float(d[i]), 3)] for i in np.argsort(-d)[:3]]}
         except Exception:           # an older build of the library (HMP3AMD_LIB)
             m["stream_ms"] = None
         try:
