@@ -19,22 +19,20 @@
 __global__ void k_polyphase(const int16_t *pcm, long long nsamp, const HxStream *st, const HxParams *prm,
                             const HxGlobalTabs *gt, float *sb, int NG, int SG, const float *pcmf, int nchan, int *eng, int lsf);
 __global__ void k_dcfilter(const int16_t *pcm, const float *pcm32, long long nsamp, HxStream *st, const HxParams *prm, float *pcmf, int S, int nchan);
-__global__ void k_attack_eng(const float *sb, const HxGlobalTabs *gt, int *eng, int NG, int SG, int total, int lsf);
-__global__ void k_attack_flg(const HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg,
-                             int *dbg_metric, int NG, int total, int lsf);
-__global__ void k_blocktype(HxStream *st, const unsigned char *flg, const int *eng, unsigned char *bt, unsigned char *btprev, int NG, int S);
+__global__ void k_detect(HxStream *st, const HxParams *prm, const int *eng, unsigned char *flg, int *dbg_metric, unsigned char *bt,
+                         unsigned char *btprev, int NG, int S, int lsf);
 __global__ void k_spec(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                        float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
 __global__ void k_spec_direct(const float *sb, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const unsigned char *bt,
                               float *xr, float *etab, float *thr, int *msbase, int NG, int SG);
-__global__ void k_carry(float *sb, HxStream *st, const int16_t *pcm, long long nsamp, int NG, int SG, int S, const float *pcmf, int nchan);
 __global__ void k_msscan(HxStream *st, const HxParams *prm, const int *msbase, const unsigned char *bt, unsigned char *msflag, int *msdec,
-                         const float *thr, float *thrprev, int NG, int lsf);
+                         const float *thr, float *thrprev, int NG, int lsf, float *sb, int SG, const int16_t *pcm, long long nsamp, const float *pcmf, int nchan);
 __global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned *sgn, HxBandPrep *band, const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt,
                        const unsigned char *bt, const unsigned char *msflag, const float *etab, const float *thr, const float *thrprev, int NG, long long nunits);
 __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
-                       int frames_per_stream, int NG, int lsf, long long nframes_total);
+                       int frames_per_stream, int NG, int lsf, long long nframes_total, int solo, HxStream *st_w, const int *pre_len, const int *out_bytes,
+                       const int *carry_len, unsigned *frames_out);
 __global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes, const int *carry_len, unsigned *frames_out);
 __global__ void k_pack_pre(const HxStream *st, unsigned char *out, long long out_stride, const int *pre_len);
 __global__ void k_order(const unsigned *dur, int *order, int S);
@@ -147,8 +145,6 @@ struct hx_batch {
     // chip cannot start before a stream retires (measured: 10 .. 99 % all give the same step time, 100 % loses 30 %)
     int gate_percent = 90;
     bool capturing = false;             // the pass is being recorded into a HIP graph (hx_enc_*): no timing events, nothing that queries the stream
-    hipStream_t cap_side = nullptr;     // while recording: a second stream for the chain's independent kernels (k_attack_eng beside k_polyphase, k_carry beside
-    hipEvent_t cap_ev[4] = {nullptr, nullptr, nullptr, nullptr};    // everything behind k_spec): forked and joined with these events = parallel branches of the graph
     unsigned *cap_frames = nullptr;     // one-stream encoder: where k_pack_carry leaves the stream's frame counter (next to the byte count)
     bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
     // longest-first workgroup order: 2 = for every batch with more streams than the chip has CUs (default: below that no two
@@ -513,10 +509,18 @@ static int enqueue_pack(hx_batch *b, unsigned char *d_out, long long out_stride,
     int *const x_prelen = b->d_lens + (2 * set) * (long long) b->S, *const x_carrylen = b->d_lens + (2 * set + 1) * (long long) b->S;
     const int fps = (b->lsf ? 2 : 1) * nframes;
     const long long total = (long long) S * fps;
+    // a handful of frames in all (the one-stream encoder's calls): one workgroup does the three kernels' work (hx_pack.hip, solo)
+    const int solo = (S <= 4 && total <= 8) ? S : 0;
+    if (solo) {
+        LAUNCH(k_pack, dim3(1), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
+               (const short *) x_ixq, (const unsigned *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
+               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total, solo, b->d_st, (const int *) x_prelen, (const int *) d_out_bytes, (const int *) x_carrylen, b->cap_frames);
+        return 0;
+    }
     LAUNCH(k_pack_pre, dim3(S), dim3(64), qp, (const HxStream *) b->d_st, d_out, out_stride, (const int *) x_prelen);
     LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
            (const short *) x_ixq, (const unsigned *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
-           d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total);
+           d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total, 0, (HxStream *) nullptr, (const int *) nullptr, (const int *) nullptr, (const int *) nullptr, (unsigned *) nullptr);
     LAUNCH(k_pack_carry, dim3(S), dim3(64), qp, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes, (const int *) x_carrylen, b->cap_frames);
     return 0;
 }
@@ -604,7 +608,7 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
     const int S = b->S, NG = 2 * nframes;
     const long long nsamp = 1152LL * nframes;
     // The subband carry sits in slots NG_prev..NG_prev+2 only if the previous call used another
-    // frame count; k_carry always rolls it to slots 0..2, so nothing to do here.
+    // frame count; k_msscan always rolls it to slots 0..2, so nothing to do here.
     dim3 g1(S, (NG + K1_GPB - 1) / K1_GPB);
     const int SG = 2 * b->maxF + 3;     // subband slots per (stream, channel): fixed layout
     const float *pcmf = b->any_dc ? b->d_pcmf : d_pcm32;       // fp32 samples the polyphase reads, or null for int16
@@ -623,34 +627,25 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         const float *pcmf_c = pcmf ? pcmf + o * nsamp * b->nchan : nullptr;
         unsigned char *bt_c = x_bt + o * NG;
         dim3 g1c(Sc, (NG + K1_GPB - 1) / K1_GPB);
-        int tot = Sc * 2 * 9;
-        const bool fork = b->capturing && b->cap_side;      // (recording a graph: independent kernels on a branch of their own)
-        hipStream_t q2 = fork ? b->cap_side : q;
-        if (fork) { HIPCHK(hipEventRecord(b->cap_ev[0], q)); HIPCHK(hipStreamWaitEvent(q2, b->cap_ev[0], 0)); }
-        LAUNCH(k_attack_eng, dim3((tot + 255) / 256), dim3(256), q2, sb_c, b->d_gt, eng_c, NG, SG, tot, b->lsf);
-        if (fork) HIPCHK(hipEventRecord(b->cap_ev[1], q2));
+        // (the detector energies of the carried granule are formed by k_polyphase's first tile of a stream, the carries rolled by
+        // k_msscan, flags and block types by one kernel - round 6: three launches less per call, which is what a one-stream call
+        // is made of)
         LAUNCH(k_polyphase, g1c, dim3(K1_THREADS), q, pcm_c, nsamp, st_c, b->d_prm, b->d_gt, sb_c, NG, SG, pcmf_c, b->nchan, eng_c, b->lsf);
-        if (fork) HIPCHK(hipStreamWaitEvent(q, b->cap_ev[1], 0));
-        tot = Sc * NG;
-        LAUNCH(k_attack_flg, dim3((tot + 255) / 256), dim3(256), q, st_c, b->d_prm, eng_c, b->d_flg + o * NG,
-               b->debug ? b->d_dbgmetric : nullptr, NG, tot, b->lsf);
-        LAUNCH(k_blocktype, dim3((Sc + 63) / 64), dim3(64), q, st_c, b->d_flg + o * NG, eng_c, bt_c, x_btprev + o, NG, Sc);
+        LAUNCH(k_detect, dim3((Sc + 3) / 4), dim3(256), q, st_c, b->d_prm, eng_c, b->d_flg + o * NG,
+               b->debug ? b->d_dbgmetric : nullptr, bt_c, x_btprev + o, NG, Sc, b->lsf);
         // (the form of K4 that goes with the stream-walk kernel: hx_front.hip, spec_granule)
         if (b->slim) LAUNCH(k_spec_direct, dim3((unsigned) ((long long) Sc * nframes)), dim3(128), q, sb_c, st_c, b->d_prm, b->d_gt, bt_c, x_xr + o * NG * 1152,
                             x_etab + o * NG * 128, x_thr + o * NG * 128, x_msbase + o * NG, NG, SG);
         else LAUNCH(k_spec, dim3((unsigned) ((long long) Sc * nframes)), dim3(128), q, sb_c, st_c, b->d_prm, b->d_gt, bt_c, x_xr + o * NG * 1152,
                     x_etab + o * NG * 128, x_thr + o * NG * 128, x_msbase + o * NG, NG, SG);
-        if (fork) { HIPCHK(hipEventRecord(b->cap_ev[2], q)); HIPCHK(hipStreamWaitEvent(q2, b->cap_ev[2], 0)); }
-        // stereo decisions and the pre-echo hand-over (serial per stream), then the allocator's state-independent start
+        // stereo decisions and the pre-echo hand-over (serial per stream) with the carries of the subband buffer and the PCM
+        // history (they belong to the front end: k_alloc does not touch them), then the allocator's state-independent start
         // values per granule; the magnitudes replace the spectrum in place, so the tests' tap of it is taken first
-        LAUNCH(k_msscan, dim3(Sc), dim3(64), q, st_c, b->d_prm, x_msbase + o * NG, bt_c, x_msflag + o * NG, x_msdec + o * NG, x_thr + o * NG * 128, x_thrprev + o * 128, NG, b->lsf);
+        LAUNCH(k_msscan, dim3(Sc), dim3(64), q, st_c, b->d_prm, x_msbase + o * NG, bt_c, x_msflag + o * NG, x_msdec + o * NG, x_thr + o * NG * 128, x_thrprev + o * 128, NG, b->lsf,
+               sb_c, SG, pcm_c, nsamp, pcmf_c, b->nchan);
         LAUNCH(k_prep, dim3((unsigned) (((long long) Sc * NG + 3) / 4)), dim3(256), q, (const float *) (x_xr + o * NG * 1152), (b->debug && b->d_xrdbg) ? b->d_xrdbg : (float *) nullptr, b->debug ? x_x34 : (float *) nullptr,
                x_sgn + o * NG * 2 * HX_SGN_WORDS, x_band + o * NG, st_c, b->d_prm, b->d_gt, bt_c, x_msflag + o * NG,
                x_etab + o * NG * 128, x_thr + o * NG * 128, x_thrprev + o * 128, NG, (long long) Sc * NG);
-        // the carry of the subband buffer and the PCM history belong to the front end (k_alloc does not touch them): behind
-        // k_spec, the last reader of the carried slots, and beside everything that follows (joined at the end of the pass)
-        LAUNCH(k_carry, dim3(Sc * 2), dim3(256), q2, sb_c, st_c, pcm_c, nsamp, NG, SG, Sc, pcmf_c, b->nchan);
-        if (fork) HIPCHK(hipEventRecord(b->cap_ev[3], q2));
         return 0;
     };
     for (int s0 = 0; s0 < S; s0 += C) if (front(s0, (S - s0 < C) ? S - s0 : C) != 0) return -1;
@@ -742,7 +737,6 @@ static int encode_pass(hx_batch *b, const int16_t *d_pcm, const float *d_pcm32, 
         b->nsubmit++;
         b->inflight = true;
     }
-    if (b->capturing && b->cap_side) HIPCHK(hipStreamWaitEvent(qa, b->cap_ev[3], 0));      // the side branch joins the recorded stream
     HIPCHK(hipGetLastError());
     b->lastNG = NG;
     return 0;
@@ -1124,8 +1118,7 @@ struct hx_enc {
     // One call = one graph launch: the whole single-stream chain (PCM up, the pipeline's kernels, byte count / frame counter /
     // bitstream down) is recorded once into a HIP graph over page-locked staging buffers and replayed per call
     // (reference call being replaced: CMp3Enc::L3_audio_encode, mp3enc.cpp:2031-2073, and MP3_audio_encode, :2812-2866).
-    hipStream_t gq = nullptr, gq2 = nullptr;
-    hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t gq = nullptr;
     unsigned char *d_encbuf = nullptr;  // device: [byte count | frame counter | ... HX_ENC_GRAPH_OFF | the call's bitstream]
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -1144,8 +1137,6 @@ static void enc_graph_drop(hx_enc *e)
     if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
     if (e->gq) { hipStreamDestroy(e->gq); e->gq = nullptr; }
-    if (e->gq2) { hipStreamDestroy(e->gq2); e->gq2 = nullptr; }
-    for (int i = 0; i < 4; i++) if (e->gev[i]) { hipEventDestroy(e->gev[i]); e->gev[i] = nullptr; }
     if (e->d_encbuf) { hipFree(e->d_encbuf); e->d_encbuf = nullptr; }
     if (e->h_pcm) { hipHostFree(e->h_pcm); e->h_pcm = nullptr; }
     if (e->h_out) { hipHostFree(e->h_out); e->h_out = nullptr; }
@@ -1189,8 +1180,8 @@ extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
 
 // Record the single-stream chain of e->b into a graph (see hx_enc).  Returns 0 when e->gexec is ready.
 // Device side: one buffer [byte count | frame counter | ... 256 | bitstream], so that the call's results come down in one copy;
-// the graph's last node copies the allocator-launch counter, which the call polls.  The chain's independent kernels
-// (k_attack_eng beside k_polyphase, k_carry beside everything behind k_spec) are recorded on a second stream: parallel branches.
+// the graph's last node copies the allocator-launch counter, which the call polls.  (The chain's independent kernels as parallel
+// branches of the graph - a second recorded stream, forked and joined with events - were measured at 147 against 106 us per call.)
 static int enc_graph_build(hx_enc *e)
 {
     hx_batch *b = e->b;
@@ -1206,22 +1197,14 @@ static int enc_graph_build(hx_enc *e)
     HIPCHK(hipHostMalloc((void **) &e->h_meta, 4 * sizeof(unsigned), hipHostMallocDefault));
     HIPCHK(hipMemcpy(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
     HIPCHK(hipStreamCreateWithFlags(&e->gq, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->gq2, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&e->gev[i], hipEventDisableTiming));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipStreamBeginCapture(e->gq, hipStreamCaptureModeThreadLocal));
     int r = 0;
     b->capturing = true;
-    // (HMP3AMD_ENC_GRAPH_FORK=1: the independent kernels as parallel branches - measured slower, 130 against 104 us per call:
-    // a branch costs more in cross-queue synchronisation than the two short kernels it takes off the chain)
-    const char *fk = getenv("HMP3AMD_ENC_GRAPH_FORK");
-    b->cap_side = (fk && atoi(fk) != 0) ? e->gq2 : nullptr;
-    for (int i = 0; i < 4; i++) b->cap_ev[i] = e->gev[i];
     b->cap_frames = reinterpret_cast<unsigned *>(e->d_encbuf) + 1;
     if (hipMemcpyAsync(b->d_pcm, e->h_pcm, (size_t) pbytes, hipMemcpyHostToDevice, e->gq) != hipSuccess) r = -1;
     if (!r) r = encode_core(b, nullptr, (const float *) b->d_pcm, 1, e->d_encbuf + HX_ENC_GRAPH_OFF, stride, reinterpret_cast<int *>(e->d_encbuf), e->gq);
     b->capturing = false;
-    b->cap_side = nullptr;
     b->cap_frames = nullptr;
     const size_t head = (size_t) (stride < HX_ENC_GRAPH_HEAD ? stride : HX_ENC_GRAPH_HEAD);
     if (!r && hipMemcpyAsync(e->h_out, e->d_encbuf, HX_ENC_GRAPH_OFF + head, hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;

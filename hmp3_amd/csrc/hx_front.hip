@@ -2,16 +2,16 @@
 //   k_dcfilter   K0  optional input DC blocker, sequential per channel   (filter2.c:116-144)
 //   k_polyphase  K1  int16 / fp32 PCM -> 32 x 18 subband samples per granule (the stage of sbt.c:57-310), and in its
 //                    epilogue the subband energies in mB for the transient detector (detect.c:80-101)
-//   k_attack_eng K2a the same energies of the carried granule (the call's first detector index)
-//   k_attack_flg K2b attack metric for both "previous granule short" cases (detect.c:103-141)
-//   k_blocktype  K2c per-stream block-type state machine                (mp3enc.cpp:1398-1440)
+//                    (its first tile of a stream also forms the energies of the carried granule: the call's first detector index)
+//   k_detect     K2  attack metric for both "previous granule short" cases (detect.c:103-141) and the per-stream block-type
+//                    state machine (mp3enc.cpp:1398-1440), one wavefront per stream
 //   k_spec       K4  window + 18-point (3 x 6-point) MDCT + alias butterflies (hwin.c:147-322,
 //                    emdct.c:104-288), MDCT-energy psy model (emap.c:61-96, spdsmr.c:64-273) and the
 //                    L/R vs M/S metric (bitallo3.cpp:682-742, bitallos.cpp:377-416), one wave per granule
 //   k_msscan     K5a the frames' stereo decisions: hysteresis scan over a stream's granules (bitallo3.cpp:693-751)
 //   k_prep       K5b what the allocator's granule start needs that does not depend on its carried state: signs, band
 //                    energies, band maxima of x^(3/4), zero-gain steps, masks (bitallo3.cpp:816-1066, spdsmr.c:275-318)
-//   k_carry      K8  roll the 3-granule subband carry and the PCM history
+//                    (k_msscan also rolls the 3-granule subband carry and the PCM history into the next call)
 // Parallel over streams x channels x granules (x slots / subbands / partitions).  Each lane
 // evaluates its unit with the reference's operation order, so results are bit-identical.
 // The file is compiled twice (hmp3_amd/build.sh): HX_FRONT_PART=1 holds k_polyphase and the small kernels, HX_FRONT_PART=2
@@ -82,6 +82,20 @@ __global__ __launch_bounds__(K1_THREADS) void k_polyphase(const int16_t *__restr
     const HxStream *ss = st + s;
     const HxParams *p = prm + __builtin_amdgcn_readfirstlane(ss->cls);
     const int16_t *src = pcm + (long long) s * nsamp * nchan;   // interleaved L R (or one channel)
+    if (blockIdx.y == 0 && lt < 18) {
+        // The detector energies of eng index 0 (this kernel's epilogue writes the others): from the carried last granule of the
+        // previous call, subband slot 2, which no workgroup of this launch writes.  (A kernel of its own until round 6: eighteen
+        // lanes per stream, one launch less per call.)
+        const int ch = lt / 9, k = lt - 9 * ch;
+        const int sb0 = lsf ? 8 : 4, nsbb = lsf ? 20 : 14;
+        const float *y = sb + ((long long) (s * 2 + ch) * SG + 2) * 576 + 18 * sb0 + 2 * k;
+        float sum = 7.0e4f;
+        for (int i = 0; i < nsbb; i++, y += 18) {
+            float x = y[0] * y[0]; sum += x;
+            x = y[1] * y[1]; sum += x;
+        }
+        eng[(long long) (s * 2 + ch) * NG * 9 + k] = hx_mblog(gt->mblog, sum);
+    }
     const long long n0 = 576LL * g0 - 480;                      // sample index of staged slot 0
     const int hist = (g0 == 0) ? 480 : 0;                       // slots that come from the carry
     if (nchan == 1) {       // mono batch: the right half of every pair is silence
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_polyphase(const int16_t *__restr
     {   // transient detector input (reference detect.c:147-196): energy of subbands 4..17 (MPEG-2 LSF rates: 8..27) per pair
         // of time slots, as mB: slots 2 k (this lane) and 2 k + 1 (the next lane), subband after subband, in the reference's
         // order of additions.  eng index g <-> the granule one before coded granule g, so this granule's go to index + 1
-        // (the last granule's are next call's index 0, which k_attack_eng forms from the carry).  A mono batch's silent
+        // (the last granule's are next call's index 0, formed from the carry at the top of this kernel).  A mono batch's silent
         // second channel sums to the floor by itself.
         v2f sum = {7.0e4f, 7.0e4f};
 #define ENG_TERM(i) { const v2f y1 = {__shfl_down(X[i].x, 1, 64), __shfl_down(X[i].y, 1, 64)}; v2f x = X[i] * X[i]; sum += x; x = y1 * y1; sum += x; }
@@ -214,24 +228,6 @@ __global__ __launch_bounds__(K1_THREADS) void k_polyphase(const int16_t *__restr
             eo[(long long) NG * 9] = hx_mblog(gt->mblog, sum.y);
         }
     }
-}
-
-// The energies of eng index 0 (k_polyphase writes the others): from the carried last granule of the previous call,
-// subband slot 2.  total = S * 2 * 9.
-__global__ void k_attack_eng(const float *__restrict__ sb, const HxGlobalTabs *__restrict__ gt,
-                             int *__restrict__ eng, int NG, int SG, int total, int lsf)
-{
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    int k = id % 9, sc = id / 9;
-    const int sb0 = lsf ? 8 : 4, nsbb = lsf ? 20 : 14;
-    const float *y = sb + ((long long) sc * SG + 2) * 576 + 18 * sb0 + 2 * k;
-    float sum = 7.0e4f;
-    for (int i = 0; i < nsbb; i++, y += 18) {
-        float x = y[0] * y[0]; sum += x;
-        x = y[1] * y[1]; sum += x;
-    }
-    eng[(long long) sc * NG * 9 + k] = hx_mblog(gt->mblog, sum);
 }
 
 // attack metric of one channel at coded step g, for short_flag_prev = 0 and 1
@@ -261,75 +257,68 @@ __device__ __forceinline__ void attack_metric(const int *hist, const int *eng, i
     *m1 = r1;
 }
 
-__global__ void k_attack_flg(const HxStream *__restrict__ st, const HxParams *__restrict__ prm,
-                             const int *__restrict__ eng, unsigned char *__restrict__ flg,
-                             int *__restrict__ dbg_metric, int NG, int total, int lsf)
+// Transient flags and block types of a stream, one wavefront per stream (round 6: two kernels before - a flag per (stream,
+// granule) lane, then one lane per stream walking them): 64 granules at a time the lanes form their granule's two flags (for
+// short_flag_prev = 0 and 1), lane 0 walks the state machine over them - block_type[g] = table[prev type][short now][short
+// next] - and the lanes store the 64 types.
+__global__ __launch_bounds__(256) void k_detect(HxStream *__restrict__ st, const HxParams *__restrict__ prm,
+                                                const int *__restrict__ eng, unsigned char *__restrict__ flg,
+                                                int *__restrict__ dbg_metric, unsigned char *__restrict__ bt,
+                                                unsigned char *__restrict__ btprev, int NG, int S, int lsf)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    int g = id % NG, s = id / NG;
-    const HxStream *ss = st + s;
-    int thr = prm[ss->cls].short_block_threshold;
-    int a0, a1, b0, b1;
-    attack_metric(ss->attack_hist[0], eng + (long long) (s * 2 + 0) * NG * 9, g, &a0, &a1, lsf);
-    attack_metric(ss->attack_hist[1], eng + (long long) (s * 2 + 1) * NG * 9, g, &b0, &b1, lsf);
-    int f0 = (a0 > thr) | (b0 > thr), f1 = (a1 > thr) | (b1 > thr);
-    flg[id] = (unsigned char) (f0 | (f1 << 1));
-    if (dbg_metric) { dbg_metric[id * 2] = a0; dbg_metric[id * 2 + 1] = b0; }
-}
-
-// serial per stream: block_type[g] = table[prev type][short now][short next]
-__global__ void k_blocktype(HxStream *__restrict__ st, const unsigned char *__restrict__ flg,
-                            const int *__restrict__ eng, unsigned char *__restrict__ bt,
-                            unsigned char *__restrict__ btprev, int NG, int S)
-{
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+    __shared__ unsigned char sflg[4][64], sbt[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wv;
+    if (s >= S) return;         // (wave-uniform; nothing below is a workgroup barrier)
+    HxStream *ss = st + s;
+    const int thr = prm[ss->cls].short_block_threshold;
     // sel[prev type * 4 + short now * 2 + short next] = {0, 1, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 0, 1, 2, 2} as nibbles of a constant
     const unsigned long long sel = 0x2210222322232210ull;
-    HxStream *ss = st + s;
     int prev_next = ss->short_flag_next_prev, prev_bt = ss->bt_prev;
-    btprev[s] = (unsigned char) prev_bt;
-    const unsigned char *fs = flg + (long long) s * NG;
-    unsigned char *bo = bt + (long long) s * NG;
-    auto step = [&](int f) {
-        const int next = prev_next ? (f >> 1) & 1 : f & 1;
-        const int b = (int) ((sel >> (4 * (prev_bt * 4 + prev_next * 2 + next))) & 15);
-        prev_bt = b;
-        prev_next = next;
-        return (unsigned) b;
-    };
-    int g = 0;
-    // sixteen granules per load and store (NG is even; the rows of flg / bt are 16-byte aligned when NG % 16 == 0)
-    if ((NG & 15) == 0)
-        for (; g + 16 <= NG; g += 16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(fs + g);
-            const unsigned in[4] = {v.x, v.y, v.z, v.w};
-            unsigned o[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                unsigned r = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) r |= step((int) ((in[q] >> (8 * e)) & 255)) << (8 * e);
-                o[q] = r;
+    if (lane == 0) btprev[s] = (unsigned char) prev_bt;
+    const int *e0 = eng + (long long) (s * 2 + 0) * NG * 9, *e1 = eng + (long long) (s * 2 + 1) * NG * 9;
+    for (int gb = 0; gb < NG; gb += 64) {
+        const int g = gb + lane;
+        if (g < NG) {
+            int a0, a1, b0, b1;
+            attack_metric(ss->attack_hist[0], e0, g, &a0, &a1, lsf);
+            attack_metric(ss->attack_hist[1], e1, g, &b0, &b1, lsf);
+            const int f0 = (a0 > thr) | (b0 > thr), f1 = (a1 > thr) | (b1 > thr);
+            const unsigned char f = (unsigned char) (f0 | (f1 << 1));
+            sflg[wv][lane] = f;
+            flg[(long long) s * NG + g] = f;
+            if (dbg_metric) { dbg_metric[((long long) s * NG + g) * 2] = a0; dbg_metric[((long long) s * NG + g) * 2 + 1] = b0; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int n = min(64, NG - gb);
+            for (int k = 0; k < n; k++) {
+                const int f = sflg[wv][k];
+                const int next = prev_next ? (f >> 1) & 1 : f & 1;
+                const int b = (int) ((sel >> (4 * (prev_bt * 4 + prev_next * 2 + next))) & 15);
+                prev_bt = b;
+                prev_next = next;
+                sbt[wv][k] = (unsigned char) b;
             }
-            *reinterpret_cast<uint4 *>(bo + g) = make_uint4(o[0], o[1], o[2], o[3]);
         }
-    for (; g < NG; g++) bo[g] = (unsigned char) step(fs[g]);
-    ss->short_flag_next_prev = prev_next;
-    ss->bt_prev = prev_bt;
-    // roll the energy history: last 32 values of [hist | eng]
-    for (int c = 0; c < 2; c++) {
-        int tmp[32];
-        const int *e = eng + (long long) (s * 2 + c) * NG * 9;
-        for (int j = 0; j < 32; j++) {
-            int a = 9 * NG + j;
-            tmp[j] = (a < 32) ? ss->attack_hist[c][a] : e[a - 32];
-        }
-        for (int j = 0; j < 32; j++) ss->attack_hist[c][j] = tmp[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (g < NG) bt[(long long) s * NG + g] = sbt[wv][lane];
+        __builtin_amdgcn_wave_barrier();
     }
+    // roll the energy history: last 32 values of [hist | eng] (every lane has read the history above)
+    int keep = 0;
+    const int c = lane >> 5, j = lane & 31;
+    {
+        const int *e = c ? e1 : e0;
+        const int a = 9 * NG + j;
+        keep = (a < 32) ? ss->attack_hist[c][a] : e[a - 32];
+    }
+    __builtin_amdgcn_wave_barrier();
+    ss->attack_hist[c][j] = keep;
+    if (lane == 0) { ss->short_flag_next_prev = prev_next; ss->bt_prev = prev_bt; }
 }
-
 #endif      // HX_FRONT_PART & 1
 #if HX_FRONT_PART & 2
 // ---- MDCT kernels ------------------------------------------------------------------------------------
@@ -841,9 +830,14 @@ HX_K4(k_spec_direct, true)
 // previous long granule; a short granule takes none and clears it (reference bitallo3.cpp:693-698,743-751); an
 // MPEG-1 frame is coded M/S when its two granules' values sum to >= 0 (mp3enc.cpp:1538-1546), an MPEG-2 frame by
 // its one granule.  Depends on front-end data only, so it runs here and not in the per-stream allocator walk.
+// (Round 6: the kernel also rolls the stream's carries - the last three granules of subband samples to slots 0..2, the last 480
+// input samples into the stream state - which was k_carry's launch: k_spec, the last reader of the subband buffer, is through
+// when this kernel starts, and 63 of its 64 lanes had nothing to do.)
 __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const HxParams *__restrict__ prm, const int *__restrict__ msbase,
                                                const unsigned char *__restrict__ bt, unsigned char *__restrict__ msflag, int *__restrict__ msdec,
-                                               const float *__restrict__ thr, float *__restrict__ thrprev, int NG, int lsf)
+                                               const float *__restrict__ thr, float *__restrict__ thrprev, int NG, int lsf,
+                                               float *__restrict__ sb, int SG, const int16_t *__restrict__ pcm, long long nsamp,
+                                               const float *__restrict__ pcmf, int nchan)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     HxStream *ss = st + s;
@@ -901,6 +895,19 @@ __global__ __launch_bounds__(64) void k_msscan(HxStream *__restrict__ st, const 
         else if ((i & 63) < 12) nw = 2.0f * last[(i & 64) + 24 + (i & 63)];
         (&ss->thr_prev[0][0])[i] = nw;
     }
+    // the carries into the next call
+    for (int ch = 0; ch < 2; ch++) {
+        float *base = sb + (long long) (s * 2 + ch) * SG * 576;
+        for (int e = lane; e < 576; e += 64)
+            for (int k = 0; k < 3; k++) base[k * 576 + e] = base[(NG + k) * 576 + e];
+        const int16_t *src = pcm + (long long) s * nsamp * nchan + ch;
+        for (int i = lane; i < 480 && ch < nchan; i += 64) {
+            const long long n = nsamp - 480 + i;
+            // fewer than 480 new samples never happens (a frame is 1152), so all come from this batch
+            ss->pcm_hist[ch][i] = pcmf ? pcmf[((long long) s * nsamp + n) * nchan + ch] : (float) src[nchan * n];
+        }
+    }
+    if (lane == 0) ss->frames_in += (int) (nsamp / 1152);
 }
 
 // K5b: everything the allocator does at the start of a long-block granule that does not depend on its carried
@@ -1138,26 +1145,6 @@ __global__ __launch_bounds__(64 * PREP_GPB) void k_prep(const float *__restrict_
 
 #endif      // HX_FRONT_PART & 2
 #if HX_FRONT_PART & 1
-// After the allocator has run: roll the subband carry (last 3 granules -> slots 0..2) and the
-// last 480 input samples into the stream state.
-__global__ void k_carry(float *__restrict__ sb, HxStream *__restrict__ st, const int16_t *__restrict__ pcm,
-                        long long nsamp, int NG, int SG, int S, const float *__restrict__ pcmf, int nchan)
-{
-    const int sc = blockIdx.x;                  // s*2 + ch
-    const int s = sc >> 1, ch = sc & 1;
-    float *base = sb + (long long) sc * SG * 576;
-    for (int e = threadIdx.x; e < 576; e += blockDim.x)
-        for (int k = 0; k < 3; k++) base[k * 576 + e] = base[(NG + k) * 576 + e];
-    HxStream *ss = st + s;
-    const int16_t *src = pcm + (long long) s * nsamp * nchan + ch;
-    for (int i = threadIdx.x; i < 480 && ch < nchan; i += blockDim.x) {
-        long long n = nsamp - 480 + i;
-        // fewer than 480 new samples never happens (a frame is 1152), so all come from this batch
-        ss->pcm_hist[ch][i] = pcmf ? pcmf[((long long) s * nsamp + n) * nchan + ch] : (float) src[nchan * n];
-    }
-    if (threadIdx.x == 0 && ch == 0) ss->frames_in += (int) (nsamp / 1152);
-}
-
 // K0 (only when some stream asked for it, E_CONTROL filter_select = 1): the input DC blocker
 // y = x - d, d += alpha * y (reference filter2.c:116-121,137-144).  A first-order recurrence
 // evaluated in the reference's order, so it is sequential per channel: one lane per

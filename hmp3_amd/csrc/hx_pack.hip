@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
                                               const unsigned *__restrict__ sgn, const HxSegOut *__restrict__ seg,
                                               const HxFrameOut *__restrict__ frm, const HxSlot *__restrict__ slots,
                                               unsigned char *__restrict__ out, long long out_stride, unsigned char *__restrict__ packet,
-                                              int *__restrict__ status, int frames_per_stream, int NG, int lsf, long long nframes_total)
+                                              int *__restrict__ status, int frames_per_stream, int NG, int lsf, long long nframes_total,
+                                              int solo, HxStream *__restrict__ st_w, const int *__restrict__ pre_len, const int *__restrict__ out_bytes,
+                                              const int *__restrict__ carry_len, unsigned *__restrict__ frames_out)
 {
     __shared__ PackLds L;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform, made provably so)
@@ -198,6 +200,17 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
         L.tabpk[tid] = gt->huff_off[tid] | (dim << 12) | (lin << 20);
     }
     if (tid < 16) { L.quada_code[tid] = gt->quada_code[tid]; L.quada_len[tid] = gt->quada_len[tid]; }
+    // solo > 0 (a handful of frames in all - the one-stream encoder's calls: hx_cabi.hip launches ONE workgroup): this
+    // workgroup also does what k_pack_pre and k_pack_carry do for the call's `solo` streams - the pending frames' images to the
+    // head of `out` before the packing, the incomplete ones' back into the stream state behind it - two launches less per call.
+    if (solo > 0) {
+        for (int s = 0; s < solo; s++) {
+            unsigned char *dst = out + (long long) s * out_stride;
+            const int n = pre_len[s];
+            for (int i = tid; i < n; i += 256) dst[i] = st_w[s].main_buf[i];      // (st_w: the pointer the images go back through below)
+        }
+        __syncthreads();
+    }
     for (long long fr = blockIdx.x; fr < nframes_total; fr += gridDim.x) {
         const int s = (int) (fr / frames_per_stream), f = (int) (fr % frames_per_stream);
         for (int i = tid; i < 640; i += 256) L.bitw[i] = 0;
@@ -274,6 +287,16 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
         if (fo.packet_off >= 0)     // *_Packet outputs: the unpadded main data behind the packet's own header and side info
             for (int i = tid; i < fo.raw_bytes; i += 256) packet[fo.packet_off + i] = (unsigned char) (L.bitw[i >> 2] >> (24 - 8 * (i & 3)));
         __syncthreads();            // the bit buffer is cleared for the next frame
+    }
+    if (solo > 0) {
+        // (every byte of `out` this workgroup wrote is visible to it behind the barrier above: one CU, one L1)
+        for (int s = 0; s < solo; s++) {
+            HxStream *ss = st_w + s;
+            if (frames_out && tid == 0) frames_out[s] = ss->tot_frames_out;
+            const unsigned char *src = out + (long long) s * out_stride + out_bytes[s];
+            const int n = carry_len[s];
+            for (int i = tid; i < n; i += 256) ss->main_buf[i] = src[i];
+        }
     }
 }
 

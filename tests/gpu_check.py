@@ -79,7 +79,7 @@ def main():
     NG = 2 * F
     SG = NG + 3
     sb = b.debug_read("sb", np.float32, S * 2 * SG * 576).reshape(S, 2, SG, 576)
-    # k_carry has rolled the buffer: slots 0..2 now hold the last three granules
+    # k_msscan has rolled the buffer: slots 0..2 now hold the last three granules
     xr = b.debug_read("xr", np.float32, S * NG * 1152).reshape(S, NG, 2, 576)
     etab = b.debug_read("etab", np.float32, S * NG * 128).reshape(S, NG, 2, 64)
     thr = b.debug_read("thr", np.float32, S * NG * 128).reshape(S, NG, 2, 64)

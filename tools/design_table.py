@@ -40,7 +40,7 @@ def pmc(cfg, shape):
 
 
 s2, s3, p2, p3 = stats(2), stats(3), pmc(2, "1024x256"), pmc(3, "4096x256")
-order = ["k_polyphase", "k_spec", "k_spec_direct", "k_prep", "k_alloc", "k_alloc_slim", "k_pack", "k_msscan", "k_blocktype", "k_attack_flg", "k_attack_eng", "k_carry", "k_pack_carry", "k_pack_pre", "k_order"]
+order = ["k_polyphase", "k_spec", "k_spec_direct", "k_prep", "k_alloc", "k_alloc_slim", "k_pack", "k_msscan", "k_detect", "k_pack_carry", "k_pack_pre", "k_order"]
 print("| kernel | VGPRs | LDS B | scratch B | ms cfg 2 | ms cfg 3 | GB cfg 2 | GB cfg 3 | vector issue | waiting | LDS conflicts |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 tot2 = tot3 = 0.0
