@@ -32,7 +32,7 @@ __global__ void k_prep(const float *xr, float *xmag_dbg, float *x34o, unsigned *
 __global__ void k_pack(const HxStream *st, const HxParams *prm, const HxGlobalTabs *gt, const short *ixq, const unsigned *sgn, const HxSegOut *seg,
                        const HxFrameOut *frm, const HxSlot *slots, unsigned char *out, long long out_stride, unsigned char *packet, int *status,
                        int frames_per_stream, int NG, int lsf, long long nframes_total, int solo, HxStream *st_w, const int *pre_len, const int *out_bytes,
-                       const int *carry_len, unsigned *frames_out);
+                       const int *carry_len, unsigned *frames_out, unsigned char *host_out, const int *seq_src);
 __global__ void k_pack_carry(HxStream *st, const unsigned char *out, long long out_stride, const int *out_bytes, const int *carry_len, unsigned *frames_out);
 __global__ void k_pack_pre(const HxStream *st, unsigned char *out, long long out_stride, const int *pre_len);
 __global__ void k_order(const unsigned *dur, int *order, int S);
@@ -146,6 +146,7 @@ struct hx_batch {
     int gate_percent = 90;
     bool capturing = false;             // the pass is being recorded into a HIP graph (hx_enc_*): no timing events, nothing that queries the stream
     unsigned *cap_frames = nullptr;     // one-stream encoder: where k_pack_carry leaves the stream's frame counter (next to the byte count)
+    unsigned char *cap_host = nullptr;  // one-stream encoder: page-locked host memory the packing workgroup publishes the call's results to (hx_pack.hip)
     bool poisoned = false;              // a HIP call failed in the middle of a pass: the event bookkeeping is incomplete, further calls are refused
     // longest-first workgroup order: 2 = for every batch with more streams than the chip has CUs (default: below that no two
     // streams share a CU and the order decides nothing), 3 = always (tests), 1 = only for batches beyond the resident set,
@@ -514,13 +515,14 @@ static int enqueue_pack(hx_batch *b, unsigned char *d_out, long long out_stride,
     if (solo) {
         LAUNCH(k_pack, dim3(1), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
                (const short *) x_ixq, (const unsigned *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
-               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total, solo, b->d_st, (const int *) x_prelen, (const int *) d_out_bytes, (const int *) x_carrylen, b->cap_frames);
+               d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total, solo, b->d_st, (const int *) x_prelen, (const int *) d_out_bytes, (const int *) x_carrylen, b->cap_frames,
+               (solo == 1) ? b->cap_host : (unsigned char *) nullptr, (const int *) (b->d_done + 2));
         return 0;
     }
     LAUNCH(k_pack_pre, dim3(S), dim3(64), qp, (const HxStream *) b->d_st, d_out, out_stride, (const int *) x_prelen);
     LAUNCH(k_pack, dim3((unsigned) (total < 8LL * 256 * 8 ? total : 8LL * 256 * 8)), dim3(256), qp, (const HxStream *) b->d_st, (const HxParams *) b->d_prm, (const HxGlobalTabs *) b->d_gt,
            (const short *) x_ixq, (const unsigned *) x_sgn, (const HxSegOut *) x_seg, (const HxFrameOut *) x_frm, (const HxSlot *) x_slots,
-           d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total, 0, (HxStream *) nullptr, (const int *) nullptr, (const int *) nullptr, (const int *) nullptr, (unsigned *) nullptr);
+           d_out, out_stride, b->pk_buf, b->d_status, fps, NG, b->lsf, total, 0, (HxStream *) nullptr, (const int *) nullptr, (const int *) nullptr, (const int *) nullptr, (unsigned *) nullptr, (unsigned char *) nullptr, (const int *) nullptr);
     LAUNCH(k_pack_carry, dim3(S), dim3(64), qp, b->d_st, (const unsigned char *) d_out, out_stride, (const int *) d_out_bytes, (const int *) x_carrylen, b->cap_frames);
     return 0;
 }
@@ -1123,13 +1125,11 @@ struct hx_enc {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     float *h_pcm = nullptr;             // page-locked: one 1152-sample block, float at int16 scale
-    unsigned char *h_out = nullptr;     // page-locked: image of the head of d_encbuf (HX_ENC_GRAPH_HEAD bytes of bitstream; the rest is fetched when a call emits more)
-    unsigned *h_meta = nullptr;         // page-locked: [2] allocator launches so far (the graph's last copy: changes with every replay)
+    unsigned char *h_out = nullptr;     // page-locked, coherent: [byte count | frame counter | sequence word | ... 256 | the call's bitstream], written by the packing workgroup
     int graph_state = 0;                // 0 = not built yet, 1 = ready, -1 = not available (disabled, or the build failed: plain calls)
     bool spin_off = false;              // HMP3AMD_ENC_GRAPH=2: always wait with hipStreamSynchronize (A/B of the wait)
     int plain_calls = 0;                // calls made the plain way since init (the first ones: they also load the kernels' code objects)
 };
-#define HX_ENC_GRAPH_HEAD 8192
 #define HX_ENC_GRAPH_OFF 256
 
 static void enc_graph_drop(hx_enc *e)
@@ -1140,7 +1140,6 @@ static void enc_graph_drop(hx_enc *e)
     if (e->d_encbuf) { hipFree(e->d_encbuf); e->d_encbuf = nullptr; }
     if (e->h_pcm) { hipHostFree(e->h_pcm); e->h_pcm = nullptr; }
     if (e->h_out) { hipHostFree(e->h_out); e->h_out = nullptr; }
-    if (e->h_meta) { hipHostFree(e->h_meta); e->h_meta = nullptr; }
     e->graph_state = 0;
     e->plain_calls = 0;
 }
@@ -1179,9 +1178,9 @@ extern "C" int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec)
 }
 
 // Record the single-stream chain of e->b into a graph (see hx_enc).  Returns 0 when e->gexec is ready.
-// Device side: one buffer [byte count | frame counter | ... 256 | bitstream], so that the call's results come down in one copy;
-// the graph's last node copies the allocator-launch counter, which the call polls.  (The chain's independent kernels as parallel
-// branches of the graph - a second recorded stream, forked and joined with events - were measured at 147 against 106 us per call.)
+// The graph is the PCM's copy up from page-locked staging and the pipeline's kernels; the call's results - byte count, frame
+// counter, bitstream - are written to page-locked host memory by the packing workgroup itself, which publishes a sequence word
+// behind system-scope fences (hx_pack.hip, k_pack solo): the call polls that word.
 static int enc_graph_build(hx_enc *e)
 {
     hx_batch *b = e->b;
@@ -1193,24 +1192,21 @@ static int enc_graph_build(hx_enc *e)
     HIPCHK(hipMalloc((void **) &e->d_encbuf, (size_t) (HX_ENC_GRAPH_OFF + stride)));
     HIPCHK(hipMemset(e->d_encbuf, 0, (size_t) (HX_ENC_GRAPH_OFF + stride)));
     HIPCHK(hipHostMalloc((void **) &e->h_pcm, (size_t) pbytes, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **) &e->h_out, HX_ENC_GRAPH_OFF + HX_ENC_GRAPH_HEAD, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **) &e->h_meta, 4 * sizeof(unsigned), hipHostMallocDefault));
-    HIPCHK(hipMemcpy(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIPCHK(hipHostMalloc((void **) &e->h_out, (size_t) (HX_ENC_GRAPH_OFF + stride + 16), hipHostMallocCoherent));
+    memset(e->h_out, 0, (size_t) (HX_ENC_GRAPH_OFF + stride + 16));
+    HIPCHK(hipMemcpy(e->h_out + 8, b->d_done + 2, sizeof(int), hipMemcpyDeviceToHost));       // the sequence word as the device has it now
     HIPCHK(hipStreamCreateWithFlags(&e->gq, hipStreamNonBlocking));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipStreamBeginCapture(e->gq, hipStreamCaptureModeThreadLocal));
     int r = 0;
     b->capturing = true;
     b->cap_frames = reinterpret_cast<unsigned *>(e->d_encbuf) + 1;
+    b->cap_host = e->h_out;
     if (hipMemcpyAsync(b->d_pcm, e->h_pcm, (size_t) pbytes, hipMemcpyHostToDevice, e->gq) != hipSuccess) r = -1;
     if (!r) r = encode_core(b, nullptr, (const float *) b->d_pcm, 1, e->d_encbuf + HX_ENC_GRAPH_OFF, stride, reinterpret_cast<int *>(e->d_encbuf), e->gq);
     b->capturing = false;
     b->cap_frames = nullptr;
-    const size_t head = (size_t) (stride < HX_ENC_GRAPH_HEAD ? stride : HX_ENC_GRAPH_HEAD);
-    if (!r && hipMemcpyAsync(e->h_out, e->d_encbuf, HX_ENC_GRAPH_OFF + head, hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
-    // last node: the count of allocator workgroups started so far (one more per call of a one-stream batch).  The copies of a
-    // recorded stream run in order, so when this word changes in host memory the call's other results have landed.
-    if (!r && hipMemcpyAsync(&e->h_meta[2], b->d_done + 2, sizeof(unsigned), hipMemcpyDeviceToHost, e->gq) != hipSuccess) r = -1;
+    b->cap_host = nullptr;
     hipGraph_t g = nullptr;
     const hipError_t ce = hipStreamEndCapture(e->gq, &g);       // (always ended, also after a failure inside)
     if (r || ce != hipSuccess || !g) { if (g) hipGraphDestroy(g); (void) hipGetLastError(); set_err("recording the single-stream graph failed"); return -1; }
@@ -1243,15 +1239,16 @@ static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned cha
     }
     if (!plain && e->graph_state == 1) {
         memcpy(e->h_pcm, pcm, (size_t) 1152 * b->nchan * sizeof(float));
-        const volatile unsigned *seq = &e->h_meta[2];
-        const unsigned before = *seq;
+        const volatile int *seq = reinterpret_cast<const volatile int *>(e->h_out) + 2;
+        const int before = *seq;
         bool ok = hipGraphLaunch(e->gexec, e->gq) == hipSuccess;
         if (ok) {
-            // wait on the graph's last copy in page-locked memory (a few microseconds sooner than the runtime's own wait);
-            // after 2 ms - a descheduled process, a contended device - leave the waiting to the runtime
+            // wait on the sequence word the packing workgroup publishes behind its results (a few microseconds sooner than the
+            // runtime's own wait); after 2 ms - a descheduled process, a contended device - leave the waiting to the runtime,
+            // behind which the kernel's writes are complete as well
             const auto t0 = std::chrono::steady_clock::now();
             int spins = 0;
-            while (*seq == before) {
+            while (!e->spin_off && *seq == before) {
                 __builtin_ia32_pause();
                 if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
             }
@@ -1259,14 +1256,13 @@ static HX_IN_OUT encode_one(hx_enc *e, const void *pcm, int is_f32, unsigned cha
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (ok) {
-            nb = *reinterpret_cast<const int *>(e->h_out);
-            const int head = nb < HX_ENC_GRAPH_HEAD ? nb : HX_ENC_GRAPH_HEAD;
-            memcpy(bs_out, e->h_out + HX_ENC_GRAPH_OFF, (size_t) head);
-            if (nb > head) hipMemcpy(bs_out + head, e->d_encbuf + HX_ENC_GRAPH_OFF + head, (size_t) (nb - head), hipMemcpyDeviceToHost);    // (several frames released at once)
+            nb = *reinterpret_cast<const volatile int *>(e->h_out);
+            if (nb < 0 || nb > (int) e->outbuf.size()) nb = 0;      // (cannot happen: the byte count is bounded by the stride)
+            memcpy(bs_out, e->h_out + HX_ENC_GRAPH_OFF, (size_t) nb);
             x.out_bytes = nb;
             e->bytes += nb;
             e->ave = e->ave + ((((nb << 8) - e->ave)) >> (e->p.h_id ? 7 : 6));    // mp3enc.cpp:2328 / :2589
-            e->frames = reinterpret_cast<const unsigned *>(e->h_out)[1];
+            e->frames = reinterpret_cast<const volatile unsigned *>(e->h_out)[1];
         } else {
             (void) hipGetLastError();
             set_err("replaying the single-stream graph failed");

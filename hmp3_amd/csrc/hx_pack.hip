@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
                                               unsigned char *__restrict__ out, long long out_stride, unsigned char *__restrict__ packet,
                                               int *__restrict__ status, int frames_per_stream, int NG, int lsf, long long nframes_total,
                                               int solo, HxStream *__restrict__ st_w, const int *__restrict__ pre_len, const int *__restrict__ out_bytes,
-                                              const int *__restrict__ carry_len, unsigned *__restrict__ frames_out)
+                                              const int *__restrict__ carry_len, unsigned *__restrict__ frames_out,
+                                              unsigned char *__restrict__ host_out, const int *__restrict__ seq_src)
 {
     __shared__ PackLds L;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform, made provably so)
@@ -296,6 +297,25 @@ __global__ __launch_bounds__(256) void k_pack(const HxStream *__restrict__ st, c
             const unsigned char *src = out + (long long) s * out_stride + out_bytes[s];
             const int n = carry_len[s];
             for (int i = tid; i < n; i += 256) ss->main_buf[i] = src[i];
+        }
+        // The one-stream encoder's graph (hx_cabi.hip, hx_enc): the call's results go straight to page-locked host memory -
+        // [byte count | frame counter | sequence word | ... 256 | bitstream] - and the sequence word last, behind system-scope
+        // fences: when the host sees it change, the rest has landed.  (Round 6 first had copy nodes bring the results down and
+        // polled the last of them: one call in 20 000 read the bytes before the copy ahead of it had landed - copies of one
+        // stream complete in order on the device, their writes do not arrive in order in host memory.)
+        if (host_out) {
+            const int nb = out_bytes[0];
+            const uint4 *src16 = reinterpret_cast<const uint4 *>(out);
+            uint4 *dst16 = reinterpret_cast<uint4 *>(host_out + 256);
+            for (int i = tid; i < (nb + 15) / 16; i += 256) dst16[i] = src16[i];
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) {
+                reinterpret_cast<int *>(host_out)[0] = nb;
+                reinterpret_cast<unsigned *>(host_out)[1] = st_w[0].tot_frames_out;
+                __threadfence_system();
+                __hip_atomic_store(reinterpret_cast<int *>(host_out) + 2, *seq_src, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

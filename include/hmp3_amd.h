@@ -55,9 +55,10 @@ void hx_enc_destroy(hx_enc *e);                             /* CMp3Enc::~CMp3Enc
 int hx_enc_L3_audio_encode_init(hx_enc *e, const HX_E_CONTROL *ec);
 /* CMp3Enc::L3_audio_encode (mp3enc.cpp:2031): 1152 x 2 floats at int16 scale, oldest first.
    From the third call on a call is one HIP-graph launch: the encoder's single-stream chain (PCM up from page-locked staging,
-   the pipeline's kernels, byte count / frame counter / bitstream down) is recorded once and replayed; the bytes per call are
-   those of the plain calls.  The *_Packet calls take the plain path; the environment variable HMP3AMD_ENC_GRAPH=0 restores it
-   for every call (2: replay, but wait with hipStreamSynchronize instead of polling the graph's last copy). */
+   the pipeline's kernels, whose last workgroup writes byte count / frame counter / bitstream to page-locked host memory and
+   publishes a sequence word behind them) is recorded once and replayed; the bytes per call are those of the plain calls.
+   The *_Packet calls take the plain path; the environment variable HMP3AMD_ENC_GRAPH=0 restores it for every call (2: replay,
+   but wait with hipStreamSynchronize instead of polling the sequence word). */
 HX_IN_OUT hx_enc_L3_audio_encode(hx_enc *e, const float *pcm, unsigned char *bs_out);
 /* CMp3Enc::MP3_audio_encode_init (mp3enc.cpp:2655): 8/16/24/32-bit PCM or 32-bit float source at
    8 - 48 kHz, converted to the encode rate by the built-in converter; returns min input bytes per call or 0 */

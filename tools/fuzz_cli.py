@@ -64,7 +64,9 @@ with tempfile.TemporaryDirectory() as d:
                 if os.path.exists(f):
                     os.remove(f)
     wav, a, b = os.path.join(d, "in.wav"), os.path.join(d, "ref.mp3"), os.path.join(d, "gpu.mp3")
+    it = -1
     while not BATCH and done < n_cases:
+        it += 1         # (the generator's iteration: FUZZ_CLI_ONLY names a case by it)
         sr = int(rs.choice([8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000]))
         mono = rs.rand() < 0.3
         fmt = [False, True, 8, 24, 32][int(rs.randint(0, 5))]          # 16-bit, float, 8 / 24 / 32-bit integer
@@ -99,6 +101,30 @@ with tempfile.TemporaryDirectory() as d:
             if os.path.exists(f):
                 os.remove(f)
         r1 = subprocess.run([REF, wav, a] + flags, capture_output=True)
+        # FUZZ_CLI_ONLY=<iteration>,<repeats>: that case alone, the GPU side run <repeats> times (hunting a timing-dependent difference)
+        only = os.environ.get("FUZZ_CLI_ONLY")
+        if only:
+            k_only, reps = (int(x) for x in only.split(","))
+            piped = rs.rand() < 0.33
+            okr = os.path.exists(a) and os.path.getsize(a) > 0
+            if it != k_only:
+                done += 1 if okr else 0
+                continue
+            want = open(a, "rb").read()
+            nbad = 0
+            for r in range(reps):
+                if os.path.exists(b):
+                    os.remove(b)
+                subprocess.run([CLI, wav, b] + flags, capture_output=True)
+                got = open(b, "rb").read() if os.path.exists(b) else b""
+                if got != want:
+                    nbad += 1
+                    if nbad <= 3:
+                        n = min(len(got), len(want))
+                        first = next((i for i in range(n) if got[i] != want[i]), n)
+                        print("  repeat %d: %d bytes against %d, first difference at byte %d" % (r, len(got), len(want), first))
+            print("case %d (sr %d mono %s fmt %s flags %s): %d of %d runs differ" % (k_only, sr, mono, fmt, " ".join(flags), nbad, reps))
+            sys.exit(1 if nbad else 0)
         if rs.rand() < 0.33:
             with open(wav, "rb") as fh:
                 r2 = subprocess.run([CLI, "-", b] + flags, stdin=fh, capture_output=True)
