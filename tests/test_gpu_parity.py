@@ -1129,6 +1129,29 @@ def test_cmp3enc_surface_single_stream():
     e.close()
 
 
+@pytest.mark.one_k6_build
+def test_per_frame_graph_calls_never_hand_back_stale_results():
+    """hx_enc_* replays one HIP graph per call and picks the call's results up from page-locked host memory, where the packing
+    workgroup puts them with a sequence word behind system-scope fences.  (Round 6's first form polled the last of the graph's
+    device-to-host copy nodes and read what the copy ahead of it had brought down: one call in 20 000 saw a stale byte count
+    or stale bytes - copies complete in order on the device, their writes do not land in order in host memory.)  200 encoders x
+    40 calls of an MPEG-2 mono VBR stream (two frames per call, sizes that change from call to call, so a stale byte count
+    shows) against the oracle, every call's bytes."""
+    a = api()
+    kw = dict(samprate=24000, mode=3, vbr_mnr=15, short_block_threshold=2000)
+    F = 40
+    pcm = synth.stream_pcm(377305, F, sr=24000, rho=0.0, bursts=True)[:, 0].copy()
+    enc = O.OracleEncoder(O.default_control(**kw))
+    want = [enc.encode_f32(pcm[f * 1152:(f + 1) * 1152].astype(np.float32)) for f in range(F)]
+    assert len(set(len(w) for w in want)) > 4           # the byte count moves from call to call
+    for rep in range(200):
+        e = a.Mp3Enc()
+        assert e.L3_audio_encode_init(a.default_control(**kw)) == 4608
+        got = [e.L3_audio_encode(pcm[f * 1152:(f + 1) * 1152].astype(np.float32))[1] for f in range(F)]
+        e.close()
+        assert got == want, "encoder %d: call %d differs" % (rep, next(i for i in range(F) if got[i] != want[i]))
+
+
 def test_full_size_config2_properties():
     """BASELINE configs[1] at full size (1024 streams x 256 frames): frame structure, padding
     sequence, determinism, and byte equality with the oracle on a random subset of streams."""
