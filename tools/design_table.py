@@ -2,8 +2,9 @@
    python tools/design_table.py r04 [--listings DIR]
 Per kernel and BASELINE config (2 = 1024 x 256, 3 = 4096 x 256): mean duration in the bench run (rocprofv3 --kernel-trace
 --stats; under the overlap, so a front-end kernel's duration includes its wait for the allocator's LDS), HBM bytes per launch
-(2 x FETCH_SIZE + WRITE_SIZE), vector-issue share (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), waiting share (SQ_WAIT_ANY /
-SQ_WAVE_CYCLES), LDS bank-conflict share (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); VGPRs, LDS bytes and scratch bytes from the
+(2 x FETCH_SIZE + WRITE_SIZE), vector-issue share per wave (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: a wave64 instruction holds its
+wave 4 cycles) and at the SIMD (2 x SQ_INSTS_VALU / (1024 SIMDs x busy cycles): it holds the SIMD's issue port 2 cycles; busy cycles =
+SQ_BUSY_CYCLES / 32, the counter being the sum over the chip's 32 shader engines), waiting share (SQ_WAIT_ANY / SQ_WAVE_CYCLES), LDS bank-conflict share (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); VGPRs, LDS bytes and scratch bytes from the
 code objects' metadata (listings compiled with the product's flags by tools/check_lds_flat.py --keep)."""
 import csv
 import json
@@ -41,8 +42,8 @@ def pmc(cfg, shape):
 
 s2, s3, p2, p3 = stats(2), stats(3), pmc(2, "1024x256"), pmc(3, "4096x256")
 order = ["k_polyphase", "k_spec", "k_spec_direct", "k_prep", "k_alloc", "k_alloc_slim", "k_pack", "k_msscan", "k_detect", "k_pack_carry", "k_pack_pre", "k_order"]
-print("| kernel | VGPRs | LDS B | scratch B | ms cfg 2 | ms cfg 3 | GB cfg 2 | GB cfg 3 | vector issue | waiting | LDS conflicts |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+print("| kernel | VGPRs | LDS B | scratch B | ms cfg 2 | ms cfg 3 | GB cfg 2 | GB cfg 3 | vector issue per wave | at the SIMD | waiting | LDS conflicts |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 tot2 = tot3 = 0.0
 for k in order:
     r = res.get(k, {})
@@ -54,12 +55,13 @@ for k in order:
 
     def pct(a, b):
         return "%.0f %%" % (100.0 * c[a] / c[b]) if c.get(b) else "-"
-    print("| `%s` | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+    simd = "%.0f %%" % (100.0 * 2.0 * c["SQ_INSTS_VALU"] * 32.0 / (1024.0 * c["SQ_BUSY_CYCLES"])) if c.get("SQ_BUSY_CYCLES") and c.get("SQ_INSTS_VALU") else "-"
+    print("| `%s` | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
         k, r.get("vgpr", "-"), r.get("lds", "-"), r.get("scratch", "-"),
         "%.3f" % s2[k] if k in s2 else "-", "%.3f" % s3[k] if k in s3 else "-",
         "%.2f" % (g2 / 1e9) if g2 else "-", "%.2f" % (g3 / 1e9) if g3 else "-",
-        pct("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"), pct("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), pct("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")))
-print("| **step total** | | | | | | **%.2f** | **%.2f** | | | |" % (tot2 / 1e9, tot3 / 1e9))
+        pct("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"), simd, pct("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), pct("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")))
+print("| **step total** | | | | | | **%.2f** | **%.2f** | | | | |" % (tot2 / 1e9, tot3 / 1e9))
 
 
 # ---- section 5: the bench lines of the four BASELINE configurations ----
