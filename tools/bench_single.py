@@ -1,5 +1,5 @@
 """Frames per second of the one-stream CMp3Enc-shaped API (hx_enc_*): one 1152-sample block per call, host buffers,
-seven kernel launches and two PCIe copies per call.  python tools/bench_single.py [frames]"""
+one HIP-graph launch per call (HMP3AMD_ENC_GRAPH=0: plain calls - eight kernel launches and two PCIe copies).  python tools/bench_single.py [frames]"""
 import os
 import sys
 import time
