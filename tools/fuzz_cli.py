@@ -110,6 +110,9 @@ with tempfile.TemporaryDirectory() as d:
             if it != k_only:
                 done += 1 if okr else 0
                 continue
+            if not okr:
+                print("iteration %d: the reference rejects this combination (flags %s) - not a case" % (k_only, " ".join(flags)))
+                sys.exit(0)
             want = open(a, "rb").read()
             nbad = 0
             for r in range(reps):
